@@ -1,0 +1,191 @@
+// Shared helpers for the lcmhip kernels (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/lcmhip.h"
+
+namespace lcmhip {
+
+// ---- error plumbing ---------------------------------------------------------------------------
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define LCM_HIP_CHECK(expr)                                                                    \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return ::lcmhip::fail(LCMHIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+#define LCM_REQUIRE(cond, msg)                                                                 \
+    do {                                                                                       \
+        if (!(cond)) return ::lcmhip::fail(LCMHIP_ERR_INVALID, std::string(msg) + " [" #cond "]"); \
+    } while (0)
+
+#define LCM_TRY(expr)                                                                          \
+    do {                                                                                       \
+        int _r = (expr);                                                                       \
+        if (_r != LCMHIP_OK) return _r;                                                        \
+    } while (0)
+
+// ---- dtypes -------------------------------------------------------------------------------------
+struct bf16_t {
+    uint16_t bits;
+};
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+
+// Round-to-nearest-even through the compiler's cast (v_cvt_pk_bf16_f32 on gfx950; keeps NaN a NaN).
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(uint16_t, h);
+}
+
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+    static constexpr int kDtype = LCMHIP_F32;
+    __device__ static __forceinline__ float load(const float* p) { return *p; }
+    __device__ static __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <>
+struct Elem<bf16_t> {
+    static constexpr int kDtype = LCMHIP_BF16;
+    __device__ static __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(p->bits); }
+    __device__ static __forceinline__ void store(bf16_t* p, float v) { p->bits = f32_to_bf16(v); }
+};
+
+inline size_t dtype_size(int dtype) { return dtype == LCMHIP_BF16 ? 2 : 4; }
+
+// 8 consecutive elements of T as floats (16-byte loads for bf16, two for f32).
+template <typename T>
+__device__ __forceinline__ void load8(const T* p, float (&v)[8]);
+template <>
+__device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+    float4 a = *reinterpret_cast<const float4*>(p);
+    float4 b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <>
+__device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&v)[8]) {
+    uint4 u = *reinterpret_cast<const uint4*>(p);
+    uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(w[i] << 16);
+        v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void store8(T* p, const float (&v)[8]);
+template <>
+__device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <>
+__device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&v)[8]) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        w[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// ---- wave / block reductions (wave = 64 lanes) --------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// Sum over a block of NW waves; `red` is NW floats of LDS. Every thread gets the total.
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int wid = threadIdx.x >> 6;
+    __syncthreads();  // protect `red` from the previous use
+    if ((threadIdx.x & 63) == 0) red[wid] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) t += red[i];
+    return t;
+}
+
+// ---- profiling hook ---------------------------------------------------------------------------
+// A Profiler brackets launches with event pairs when enabled; see session.cpp.
+struct Profiler;
+struct ProfScope {
+    Profiler* p;
+    int slot;
+    hipStream_t st;
+    ProfScope(Profiler* p, const char* name, double bytes, double flops, hipStream_t st);
+    ~ProfScope();
+};
+
+// ---- kernel launchers (implemented in the .hip files) ---------------------------------------------
+struct GemmArgs {
+    const void* A; int lda;
+    const void* W; const void* W2;
+    const void* bias; const void* bias2;
+    const float* gate;          // (N,) fp32 or null
+    void* out; int ldo;
+    const int32_t* out_rows;    // optional row map for `out` (length M) or null
+    int M, N, K;
+    int epilogue;
+    int dtype;
+    // RESID only: rows [M, M + extra_rows) of `out` get gate[n] * extra_const[n] added
+    int extra_rows; const float* extra_const;
+};
+int launch_gemm(const GemmArgs& a, hipStream_t st);
+
+int launch_normalize(const void* x, const void* center, const void* scale, const void* cmin, const void* cmax,
+                     void* y, int64_t rows, int dim, int dtype, bool inverse, hipStream_t st);
+// fp32 in -> T out, used by the frontend: y = (x - center) / scale with T-typed center/scale.
+int launch_normalize_f32_in(const float* x, const void* center, const void* scale, void* y, int64_t rows, int dim,
+                            int dtype, hipStream_t st);
+int launch_norm_modulate(const float* x, const void* w, const void* b, const float* shift, const float* scale,
+                         void* y, int rows, int dim, int norm_kind, float eps, int dtype, hipStream_t st);
+int launch_attention(const void* q, const void* kc, const void* vc, const int32_t* slot_map, void* out, int n_docs,
+                     int s, int n_heads, int cap, int base_keys, int causal, int dtype, hipStream_t st);
+
+struct DdimScalars {
+    float sqrt_a_t, sqrt_b_t;        // sqrt(alpha_prod_t), sqrt(1 - alpha_prod_t)
+    float sqrt_a_prev, dir_coef;     // sqrt(alpha_prod_t_prev), sqrt(1 - alpha_prod_t_prev - sigma^2)
+    float guidance_scale, guidance_rescale;
+    float inv_eps_scaling;           // 1 / epsilon_scaling or 1
+    float clip_noise;
+    float clip_sample_range;         // < 0: off
+    int prediction_type;
+    int mode;                        // 0: plain step on out_cond with prediction_type; 1: CFG (eps space)
+};
+int launch_ddim_step(const float* sample, const float* out_c, const float* out_u, float* prev, float* x0, int rows,
+                     int dim, const DdimScalars& sc, hipStream_t st);
+// Final: y = x0 * scale + center (T-typed center/scale) -> fp32
+int launch_denormalize_f32_out(const float* x0, const void* center, const void* scale, float* y, int64_t rows,
+                               int dim, int dtype, hipStream_t st);
+int launch_init_latents(const float* noise, float* lat, int64_t n, float sigma, float clip, hipStream_t st);
+// q/k/v (rows, d) T: rotate q in place, write rotated k and v into the cache rows given by cache_rows.
+int launch_rope_store(void* q, const void* k, const void* v, void* kc, void* vc, const int32_t* cache_rows,
+                      const int32_t* positions, const float* cos_tab, const float* sin_tab, int rows, int d,
+                      int use_rope, int dtype, hipStream_t st);
+int launch_add_pos(float* x, const void* table, const int32_t* positions, int rows, int d, int dtype, hipStream_t st);
+int launch_fill_rows(void* cache, const void* vec, const int32_t* rows_idx, int n_rows, int d, int dtype,
+                     hipStream_t st);
+int launch_silu_cast(const float* x, void* y, int64_t n, int dtype, hipStream_t st);
+int launch_cast(const float* x, void* y, int64_t n, int dtype, hipStream_t st);
+int launch_broadcast_rows(const float* src, float* dst, int rows, int d, hipStream_t st);
+int launch_copy_rows_to_f32(const void* src, float* dst, int64_t n, int dtype, hipStream_t st);
+
+}  // namespace lcmhip

@@ -1,0 +1,518 @@
+// Bandwidth-bound kernels of the generation path: SONAR normalizer, Layer/RMS norm fused with the
+// adaLN modulation, the fused DDIM + classifier-free-guidance update, RoPE + KV-cache scatter.
+// All of them read/write 16 bytes per lane, keep statistics in fp32 and reduce with wave shuffles.
+#include "common.h"
+
+namespace lcmhip {
+
+// ------------------------------------------------------------------------------------------------
+// SONAR normalizer: y = (x - center) / scale  [clamp]   |   y = [clamp](x) * scale + center
+// ------------------------------------------------------------------------------------------------
+template <typename TI, typename TO, typename TP, bool INVERSE>
+__global__ __launch_bounds__(256) void k_normalizer(const TI* __restrict__ x, const TP* __restrict__ center,
+                                                    const TP* __restrict__ scale, const TP* __restrict__ cmin,
+                                                    const TP* __restrict__ cmax, TO* __restrict__ y, int64_t n_vec,
+                                                    int vec_per_row) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += (int64_t)gridDim.x * blockDim.x) {
+        const int col = (int)(i % vec_per_row) * 8;
+        float v[8], c[8], s[8];
+        load8<TI>(x + i * 8, v);
+        load8<TP>(center + col, c);
+        load8<TP>(scale + col, s);
+        if (cmin != nullptr) {
+            float lo[8], hi[8];
+            load8<TP>(cmin + col, lo);
+            load8<TP>(cmax + col, hi);
+            if (INVERSE) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fminf(fmaxf(v[j], lo[j]), hi[j]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = v[j] * s[j] + c[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fminf(fmaxf((v[j] - c[j]) / s[j], lo[j]), hi[j]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = INVERSE ? v[j] * s[j] + c[j] : (v[j] - c[j]) / s[j];
+        }
+        store8<TO>(y + i * 8, v);
+    }
+}
+
+static int grid_for(int64_t n_items, int block) {
+    int64_t g = (n_items + block - 1) / block;
+    if (g > 2048) g = 2048;  // 256 CUs x 8 workgroups, grid-stride over the rest
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+int launch_normalize(const void* x, const void* center, const void* scale, const void* cmin, const void* cmax,
+                     void* y, int64_t rows, int dim, int dtype, bool inverse, hipStream_t st) {
+    LCM_REQUIRE(dim % 8 == 0 && rows >= 0, "normalizer: dim must be a multiple of 8");
+    LCM_REQUIRE((cmin == nullptr) == (cmax == nullptr), "normalizer: clip_min and clip_max go together");
+    if (rows == 0) return LCMHIP_OK;
+    const int64_t n_vec = rows * (dim / 8);
+    const int g = grid_for(n_vec, 256);
+#define LCM_NORMALIZER(T, INV)                                                                             \
+    hipLaunchKernelGGL((k_normalizer<T, T, T, INV>), dim3(g), dim3(256), 0, st, (const T*)x, (const T*)center, \
+                       (const T*)scale, (const T*)cmin, (const T*)cmax, (T*)y, n_vec, dim / 8)
+    if (dtype == LCMHIP_BF16) {
+        if (inverse) LCM_NORMALIZER(bf16_t, true); else LCM_NORMALIZER(bf16_t, false);
+    } else if (dtype == LCMHIP_F32) {
+        if (inverse) LCM_NORMALIZER(float, true); else LCM_NORMALIZER(float, false);
+    } else {
+        return fail(LCMHIP_ERR_INVALID, "normalizer: unknown dtype");
+    }
+#undef LCM_NORMALIZER
+    LCM_HIP_CHECK(hipGetLastError());
+    return LCMHIP_OK;
+}
+
+int launch_normalize_f32_in(const float* x, const void* center, const void* scale, void* y, int64_t rows, int dim,
+                            int dtype, hipStream_t st) {
+    LCM_REQUIRE(dim % 8 == 0, "normalizer: dim must be a multiple of 8");
+    if (rows == 0) return LCMHIP_OK;
+    const int64_t n_vec = rows * (dim / 8);
+    const int g = grid_for(n_vec, 256);
+    if (dtype == LCMHIP_BF16)
+        hipLaunchKernelGGL((k_normalizer<float, bf16_t, bf16_t, false>), dim3(g), dim3(256), 0, st, x,
+                           (const bf16_t*)center, (const bf16_t*)scale, (const bf16_t*)nullptr,
+                           (const bf16_t*)nullptr, (bf16_t*)y, n_vec, dim / 8);
+    else
+        hipLaunchKernelGGL((k_normalizer<float, float, float, false>), dim3(g), dim3(256), 0, st, x,
+                           (const float*)center, (const float*)scale, (const float*)nullptr, (const float*)nullptr,
+                           (float*)y, n_vec, dim / 8);
+    LCM_HIP_CHECK(hipGetLastError());
+    return LCMHIP_OK;
+}
+
+int launch_denormalize_f32_out(const float* x0, const void* center, const void* scale, float* y, int64_t rows,
+                               int dim, int dtype, hipStream_t st) {
+    LCM_REQUIRE(dim % 8 == 0, "normalizer: dim must be a multiple of 8");
+    if (rows == 0) return LCMHIP_OK;
+    const int64_t n_vec = rows * (dim / 8);
+    const int g = grid_for(n_vec, 256);
+    if (dtype == LCMHIP_BF16)
+        hipLaunchKernelGGL((k_normalizer<float, float, bf16_t, true>), dim3(g), dim3(256), 0, st, x0,
+                           (const bf16_t*)center, (const bf16_t*)scale, (const bf16_t*)nullptr,
+                           (const bf16_t*)nullptr, y, n_vec, dim / 8);
+    else
+        hipLaunchKernelGGL((k_normalizer<float, float, float, true>), dim3(g), dim3(256), 0, st, x0,
+                           (const float*)center, (const float*)scale, (const float*)nullptr, (const float*)nullptr,
+                           y, n_vec, dim / 8);
+    LCM_HIP_CHECK(hipGetLastError());
+    return LCMHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Layer / RMS norm + adaLN modulation.  One workgroup (256 lanes) per row; the row stays in
+// registers between the statistics pass and the output pass (dim <= 8192).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int KIND>
+__global__ __launch_bounds__(256) void k_norm_modulate(const float* __restrict__ x, const T* __restrict__ w,
+                                                       const T* __restrict__ b, const float* __restrict__ shift,
+                                                       const float* __restrict__ scale, T* __restrict__ y, int dim,
+                                                       float eps) {
+    constexpr int MAXV = 8;  // float4 chunks per lane
+    __shared__ float red[4];
+    const int row = blockIdx.x;
+    const float* xr = x + (size_t)row * dim;
+    const int nv = dim / 4;
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = threadIdx.x + i * 256;
+        if (c < nv) {
+            v[i] = *reinterpret_cast<const float4*>(xr + c * 4);
+            if (KIND == LCMHIP_NORM_RMS)
+                s += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+            else
+                s += v[i].x + v[i].y + v[i].z + v[i].w;
+        }
+    }
+    s = block_sum<4>(s, red);
+    float mean = 0.f, rstd;
+    if (KIND == LCMHIP_NORM_RMS) {
+        rstd = rsqrtf(s / dim + eps);
+    } else {
+        mean = s / dim;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = threadIdx.x + i * 256;
+            if (c < nv) {
+                const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+                q += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
+            }
+        }
+        q = block_sum<4>(q, red);
+        rstd = rsqrtf(q / dim + eps);
+    }
+    T* yr = y + (size_t)row * dim;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = threadIdx.x + i * 256;
+        if (c < nv) {
+            const int col = c * 4;
+            float o[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = (o[j] - mean) * rstd * Elem<T>::load(w + col + j);
+                if (KIND == LCMHIP_NORM_LAYERNORM && b != nullptr) t += Elem<T>::load(b + col + j);
+                if (scale != nullptr) t = t * (1.f + scale[col + j]) + shift[col + j];
+                o[j] = t;
+            }
+            if (sizeof(T) == 4) {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(yr) + col) = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+                uint2 pk;
+                pk.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
+                pk.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(yr) + col) = pk;
+            }
+        }
+    }
+}
+
+int launch_norm_modulate(const float* x, const void* w, const void* b, const float* shift, const float* scale,
+                         void* y, int rows, int dim, int norm_kind, float eps, int dtype, hipStream_t st) {
+    LCM_REQUIRE(dim % 4 == 0 && dim <= 8192, "norm: dim must be a multiple of 4 and <= 8192");
+    LCM_REQUIRE((shift == nullptr) == (scale == nullptr), "norm: shift and scale go together");
+    LCM_REQUIRE(w != nullptr, "norm: weight required");
+    if (rows <= 0) return LCMHIP_OK;
+#define LCM_NORM(T, KIND)                                                                                      \
+    hipLaunchKernelGGL((k_norm_modulate<T, KIND>), dim3(rows), dim3(256), 0, st, x, (const T*)w, (const T*)b, shift, \
+                       scale, (T*)y, dim, eps)
+    if (dtype == LCMHIP_BF16) {
+        if (norm_kind == LCMHIP_NORM_RMS) LCM_NORM(bf16_t, LCMHIP_NORM_RMS); else LCM_NORM(bf16_t, LCMHIP_NORM_LAYERNORM);
+    } else if (dtype == LCMHIP_F32) {
+        if (norm_kind == LCMHIP_NORM_RMS) LCM_NORM(float, LCMHIP_NORM_RMS); else LCM_NORM(float, LCMHIP_NORM_LAYERNORM);
+    } else {
+        return fail(LCMHIP_ERR_INVALID, "norm: unknown dtype");
+    }
+#undef LCM_NORM
+    LCM_HIP_CHECK(hipGetLastError());
+    return LCMHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused DDIM step (+ classifier-free guidance with rescale).  One workgroup per row; dim <= 4096.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float eps_from_output(float out, float x, const DdimScalars& sc) {
+    if (sc.prediction_type == LCMHIP_PRED_EPSILON) return out;
+    if (sc.prediction_type == LCMHIP_PRED_SAMPLE) return (x - sc.sqrt_a_t * out) / sc.sqrt_b_t;
+    return sc.sqrt_a_t * out + sc.sqrt_b_t * x;  // v-prediction
+}
+
+__global__ __launch_bounds__(256) void k_ddim_step(const float* __restrict__ sample, const float* __restrict__ out_c,
+                                                   const float* __restrict__ out_u, float* __restrict__ prev,
+                                                   float* __restrict__ x0_out, int dim, DdimScalars sc) {
+    constexpr int MAXV = 4;
+    __shared__ float red[4];
+    const size_t base = (size_t)blockIdx.x * dim;
+    const int nv = dim / 4;
+    float x[MAXV][4], e[MAXV][4], x0[MAXV][4];
+    if (sc.mode == 1) {
+        // guidance in epsilon space
+        float c[MAXV][4];
+        float sum_c = 0.f, sum_g = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int ch = threadIdx.x + i * 256;
+            if (ch < nv) {
+                const float4 xv = *reinterpret_cast<const float4*>(sample + base + ch * 4);
+                const float4 cv = *reinterpret_cast<const float4*>(out_c + base + ch * 4);
+                const float4 uv = *reinterpret_cast<const float4*>(out_u + base + ch * 4);
+                const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, cs[4] = {cv.x, cv.y, cv.z, cv.w},
+                            us[4] = {uv.x, uv.y, uv.z, uv.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    x[i][j] = xs[j];
+                    const float ec = eps_from_output(cs[j], xs[j], sc);
+                    const float eu = eps_from_output(us[j], xs[j], sc);
+                    c[i][j] = ec;
+                    e[i][j] = eu + sc.guidance_scale * (ec - eu);
+                    sum_c += ec;
+                    sum_g += e[i][j];
+                }
+            }
+        }
+        const float mean_c = block_sum<4>(sum_c, red) / dim;
+        const float mean_g = block_sum<4>(sum_g, red) / dim;
+        float q_c = 0.f, q_g = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int ch = threadIdx.x + i * 256;
+            if (ch < nv) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float dc = c[i][j] - mean_c, dg = e[i][j] - mean_g;
+                    q_c += dc * dc;
+                    q_g += dg * dg;
+                }
+            }
+        }
+        // torch.std default: unbiased (n - 1)
+        const float std_pos = sqrtf(block_sum<4>(q_c, red) / (dim - 1));
+        const float std_cfg = sqrtf(block_sum<4>(q_g, red) / (dim - 1));
+        const float factor = sc.guidance_rescale * (std_pos / std_cfg) + (1.f - sc.guidance_rescale);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                e[i][j] *= factor;
+                x0[i][j] = (x[i][j] - sc.sqrt_b_t * e[i][j]) / sc.sqrt_a_t;  // step(prediction_type="epsilon")
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int ch = threadIdx.x + i * 256;
+            if (ch < nv) {
+                const float4 xv = *reinterpret_cast<const float4*>(sample + base + ch * 4);
+                const float4 cv = *reinterpret_cast<const float4*>(out_c + base + ch * 4);
+                const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, cs[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    x[i][j] = xs[j];
+                    if (sc.prediction_type == LCMHIP_PRED_EPSILON) {
+                        e[i][j] = cs[j];
+                        x0[i][j] = (xs[j] - sc.sqrt_b_t * cs[j]) / sc.sqrt_a_t;
+                    } else if (sc.prediction_type == LCMHIP_PRED_SAMPLE) {
+                        x0[i][j] = cs[j];
+                        e[i][j] = (xs[j] - sc.sqrt_a_t * cs[j]) / sc.sqrt_b_t;
+                    } else {
+                        x0[i][j] = sc.sqrt_a_t * xs[j] - sc.sqrt_b_t * cs[j];
+                        e[i][j] = sc.sqrt_a_t * cs[j] + sc.sqrt_b_t * xs[j];
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int ch = threadIdx.x + i * 256;
+        if (ch < nv) {
+            float p[4], z[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float ee = e[i][j] * sc.inv_eps_scaling;
+                float z0 = x0[i][j];
+                if (sc.clip_sample_range >= 0.f) z0 = fminf(fmaxf(z0, -sc.clip_sample_range), sc.clip_sample_range);
+                const float pr = sc.sqrt_a_prev * z0 + sc.dir_coef * ee;
+                p[j] = fminf(fmaxf(pr, -sc.clip_noise), sc.clip_noise);
+                z[j] = z0;
+            }
+            *reinterpret_cast<float4*>(prev + base + ch * 4) = make_float4(p[0], p[1], p[2], p[3]);
+            *reinterpret_cast<float4*>(x0_out + base + ch * 4) = make_float4(z[0], z[1], z[2], z[3]);
+        }
+    }
+}
+
+int launch_ddim_step(const float* sample, const float* out_c, const float* out_u, float* prev, float* x0, int rows,
+                     int dim, const DdimScalars& sc, hipStream_t st) {
+    LCM_REQUIRE(dim % 4 == 0 && dim <= 4096 && dim > 1, "ddim: dim must be a multiple of 4 and <= 4096");
+    LCM_REQUIRE(sc.mode == 0 || out_u != nullptr, "ddim: guidance needs the unconditional output");
+    if (rows <= 0) return LCMHIP_OK;
+    hipLaunchKernelGGL(k_ddim_step, dim3(rows), dim3(256), 0, st, sample, out_c, out_u, prev, x0, dim, sc);
+    LCM_HIP_CHECK(hipGetLastError());
+    return LCMHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_init_latents(const float* __restrict__ noise, float* __restrict__ lat,
+                                                      int64_t n4, float sigma, float clip) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 v = reinterpret_cast<const float4*>(noise)[i];
+        v.x = fminf(fmaxf(v.x * sigma, -clip), clip);
+        v.y = fminf(fmaxf(v.y * sigma, -clip), clip);
+        v.z = fminf(fmaxf(v.z * sigma, -clip), clip);
+        v.w = fminf(fmaxf(v.w * sigma, -clip), clip);
+        reinterpret_cast<float4*>(lat)[i] = v;
+    }
+}
+
+int launch_init_latents(const float* noise, float* lat, int64_t n, float sigma, float clip, hipStream_t st) {
+    LCM_REQUIRE(n % 4 == 0, "latents: size must be a multiple of 4");
+    if (n == 0) return LCMHIP_OK;
+    hipLaunchKernelGGL(k_init_latents, dim3(grid_for(n / 4, 256)), dim3(256), 0, st, noise, lat, n / 4, sigma, clip);
+    LCM_HIP_CHECK(hipGetLastError());
+    return LCMHIP_OK;
+}
+
+// q/k/v: (rows, d).  Rotates consecutive pairs (2i, 2i+1) of every 128-wide head of q (in place) and
+// k by the angle table row `positions[r]`, and scatters k, v to cache row `cache_rows[r]`.
+template <typename T>
+__global__ __launch_bounds__(256) void k_rope_store(T* __restrict__ q, const T* __restrict__ k,
+                                                    const T* __restrict__ v, T* __restrict__ kc, T* __restrict__ vc,
+                                                    const int32_t* __restrict__ cache_rows,
+                                                    const int32_t* __restrict__ positions,
+                                                    const float* __restrict__ cos_tab,
+                                                    const float* __restrict__ sin_tab, int d, int use_rope) {
+    const int r = blockIdx.x;
+    const size_t src = (size_t)r * d;
+    const size_t dst = (size_t)cache_rows[r] * d;
+    const int pos = positions[r];
+    for (int c = threadIdx.x * 8; c < d; c += blockDim.x * 8) {
+        float qv[8], kv[8], vv[8];
+        load8<T>(q + src + c, qv);
+        load8<T>(k + src + c, kv);
+        load8<T>(v + src + c, vv);
+        if (use_rope) {
+            const int pair0 = (c & 127) >> 1;  // pair index inside the head
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float cs = cos_tab[pos * 64 + pair0 + j], sn = sin_tab[pos * 64 + pair0 + j];
+                const float q0 = qv[2 * j], q1 = qv[2 * j + 1], k0 = kv[2 * j], k1 = kv[2 * j + 1];
+                qv[2 * j] = q0 * cs - q1 * sn;
+                qv[2 * j + 1] = q0 * sn + q1 * cs;
+                kv[2 * j] = k0 * cs - k1 * sn;
+                kv[2 * j + 1] = k0 * sn + k1 * cs;
+            }
+            store8<T>(q + src + c, qv);
+        }
+        store8<T>(kc + dst + c, kv);
+        store8<T>(vc + dst + c, vv);
+    }
+}
+
+int launch_rope_store(void* q, const void* k, const void* v, void* kc, void* vc, const int32_t* cache_rows,
+                      const int32_t* positions, const float* cos_tab, const float* sin_tab, int rows, int d,
+                      int use_rope, int dtype, hipStream_t st) {
+    LCM_REQUIRE(d % 128 == 0, "rope: model dim must be a multiple of the 128-wide head");
+    if (rows <= 0) return LCMHIP_OK;
+    if (dtype == LCMHIP_BF16)
+        hipLaunchKernelGGL((k_rope_store<bf16_t>), dim3(rows), dim3(256), 0, st, (bf16_t*)q, (const bf16_t*)k,
+                           (const bf16_t*)v, (bf16_t*)kc, (bf16_t*)vc, cache_rows, positions, cos_tab, sin_tab, d,
+                           use_rope);
+    else
+        hipLaunchKernelGGL((k_rope_store<float>), dim3(rows), dim3(256), 0, st, (float*)q, (const float*)k,
+                           (const float*)v, (float*)kc, (float*)vc, cache_rows, positions, cos_tab, sin_tab, d,
+                           use_rope);
+    LCM_HIP_CHECK(hipGetLastError());
+    return LCMHIP_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_add_pos(float* __restrict__ x, const T* __restrict__ table,
+                                                 const int32_t* __restrict__ positions, int d) {
+    const int r = blockIdx.x;
+    const T* row = table + (size_t)positions[r] * d;
+    for (int c = threadIdx.x * 8; c < d; c += blockDim.x * 8) {
+        float a[8], b[8];
+        load8<float>(x + (size_t)r * d + c, a);
+        load8<T>(row + c, b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += b[j];
+        store8<float>(x + (size_t)r * d + c, a);
+    }
+}
+
+int launch_add_pos(float* x, const void* table, const int32_t* positions, int rows, int d, int dtype, hipStream_t st) {
+    LCM_REQUIRE(d % 8 == 0, "pos: dim must be a multiple of 8");
+    if (rows <= 0) return LCMHIP_OK;
+    if (dtype == LCMHIP_BF16)
+        hipLaunchKernelGGL((k_add_pos<bf16_t>), dim3(rows), dim3(256), 0, st, x, (const bf16_t*)table, positions, d);
+    else
+        hipLaunchKernelGGL((k_add_pos<float>), dim3(rows), dim3(256), 0, st, x, (const float*)table, positions, d);
+    LCM_HIP_CHECK(hipGetLastError());
+    return LCMHIP_OK;
+}
+
+// cache[rows_idx[i]][:] = vec[:]   (vec null: zeros)
+template <typename T>
+__global__ __launch_bounds__(256) void k_fill_rows(T* __restrict__ cache, const T* __restrict__ vec,
+                                                   const int32_t* __restrict__ rows_idx, int d) {
+    T* dst = cache + (size_t)rows_idx[blockIdx.x] * d;
+    for (int c = threadIdx.x * 8; c < d; c += blockDim.x * 8) {
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (vec != nullptr) load8<T>(vec + c, a);
+        store8<T>(dst + c, a);
+    }
+}
+
+int launch_fill_rows(void* cache, const void* vec, const int32_t* rows_idx, int n_rows, int d, int dtype,
+                     hipStream_t st) {
+    LCM_REQUIRE(d % 8 == 0, "fill: dim must be a multiple of 8");
+    if (n_rows <= 0) return LCMHIP_OK;
+    if (dtype == LCMHIP_BF16)
+        hipLaunchKernelGGL((k_fill_rows<bf16_t>), dim3(n_rows), dim3(256), 0, st, (bf16_t*)cache, (const bf16_t*)vec,
+                           rows_idx, d);
+    else
+        hipLaunchKernelGGL((k_fill_rows<float>), dim3(n_rows), dim3(256), 0, st, (float*)cache, (const float*)vec,
+                           rows_idx, d);
+    LCM_HIP_CHECK(hipGetLastError());
+    return LCMHIP_OK;
+}
+
+template <typename T, bool SILU>
+__global__ __launch_bounds__(256) void k_cast(const float* __restrict__ x, T* __restrict__ y, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        float a[8];
+        load8<float>(x + i * 8, a);
+        if (SILU) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = a[j] / (1.f + __expf(-a[j]));
+        }
+        store8<T>(y + i * 8, a);
+    }
+}
+
+static int cast_impl(const float* x, void* y, int64_t n, int dtype, bool silu, hipStream_t st) {
+    LCM_REQUIRE(n % 8 == 0, "cast: size must be a multiple of 8");
+    if (n == 0) return LCMHIP_OK;
+    const int g = grid_for(n / 8, 256);
+    if (dtype == LCMHIP_BF16) {
+        if (silu) hipLaunchKernelGGL((k_cast<bf16_t, true>), dim3(g), dim3(256), 0, st, x, (bf16_t*)y, n / 8);
+        else hipLaunchKernelGGL((k_cast<bf16_t, false>), dim3(g), dim3(256), 0, st, x, (bf16_t*)y, n / 8);
+    } else {
+        if (silu) hipLaunchKernelGGL((k_cast<float, true>), dim3(g), dim3(256), 0, st, x, (float*)y, n / 8);
+        else hipLaunchKernelGGL((k_cast<float, false>), dim3(g), dim3(256), 0, st, x, (float*)y, n / 8);
+    }
+    LCM_HIP_CHECK(hipGetLastError());
+    return LCMHIP_OK;
+}
+int launch_silu_cast(const float* x, void* y, int64_t n, int dtype, hipStream_t st) { return cast_impl(x, y, n, dtype, true, st); }
+int launch_cast(const float* x, void* y, int64_t n, int dtype, hipStream_t st) { return cast_impl(x, y, n, dtype, false, st); }
+
+// dst[r][:] = src[r % src_rows][:]  (duplicates the conditional rows for the unconditional half)
+__global__ __launch_bounds__(256) void k_broadcast_rows(const float* __restrict__ src, float* __restrict__ dst,
+                                                        int src_rows, int d4) {
+    const int r = blockIdx.x;
+    const float4* s = reinterpret_cast<const float4*>(src) + (size_t)(r % src_rows) * d4;
+    float4* o = reinterpret_cast<float4*>(dst) + (size_t)r * d4;
+    for (int c = threadIdx.x; c < d4; c += blockDim.x) o[c] = s[c];
+}
+
+int launch_broadcast_rows(const float* src, float* dst, int rows, int d, hipStream_t st) {
+    // rows = number of destination rows; sources are the first rows / 2
+    LCM_REQUIRE(d % 4 == 0 && rows % 2 == 0, "broadcast: bad shape");
+    if (rows <= 0) return LCMHIP_OK;
+    hipLaunchKernelGGL(k_broadcast_rows, dim3(rows), dim3(256), 0, st, src, dst, rows / 2, d / 4);
+    LCM_HIP_CHECK(hipGetLastError());
+    return LCMHIP_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_to_f32(const T* __restrict__ x, float* __restrict__ y, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        float a[8];
+        load8<T>(x + i * 8, a);
+        store8<float>(y + i * 8, a);
+    }
+}
+
+int launch_copy_rows_to_f32(const void* src, float* dst, int64_t n, int dtype, hipStream_t st) {
+    LCM_REQUIRE(n % 8 == 0, "copy: size must be a multiple of 8");
+    if (n == 0) return LCMHIP_OK;
+    const int g = grid_for(n / 8, 256);
+    if (dtype == LCMHIP_BF16) hipLaunchKernelGGL((k_to_f32<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)src, dst, n / 8);
+    else hipLaunchKernelGGL((k_to_f32<float>), dim3(g), dim3(256), 0, st, (const float*)src, dst, n / 8);
+    LCM_HIP_CHECK(hipGetLastError());
+    return LCMHIP_OK;
+}
+
+}  // namespace lcmhip

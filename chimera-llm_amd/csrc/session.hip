@@ -1,0 +1,856 @@
+// Host side of liblcm_hip.so: weight table, per-batch session (caches + scratch carved from a
+// caller-provided workspace), the contextualizer append, the denoising loop and the C ABI.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace lcmhip {
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+// ------------------------------------------------------------------------------------------------ profiler
+struct Profiler {
+    struct Pair { hipEvent_t a, b; int row; };
+    struct Row { std::string name; int64_t launches = 0; double ms = 0, bytes = 0, flops = 0; };
+    bool enabled = false;
+    std::vector<Pair> pairs;      // pairs recorded since the last collect
+    std::vector<Pair> free_pairs;
+    std::vector<Row> rows;
+    std::map<std::string, int> index;
+
+    int begin(const char* name, double bytes, double flops, hipStream_t st) {
+        if (!enabled) return -1;
+        int r;
+        auto it = index.find(name);
+        if (it == index.end()) {
+            r = (int)rows.size();
+            index[name] = r;
+            rows.push_back(Row{name});
+        } else {
+            r = it->second;
+        }
+        rows[r].launches += 1;
+        rows[r].bytes += bytes;
+        rows[r].flops += flops;
+        Pair p;
+        if (!free_pairs.empty()) {
+            p = free_pairs.back();
+            free_pairs.pop_back();
+        } else {
+            if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return -1;
+        }
+        p.row = r;
+        (void)hipEventRecord(p.a, st);
+        pairs.push_back(p);
+        return (int)pairs.size() - 1;
+    }
+    void end(int slot, hipStream_t st) {
+        if (slot >= 0) (void)hipEventRecord(pairs[slot].b, st);
+    }
+    void collect() {
+        for (auto& p : pairs) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) rows[p.row].ms += ms;
+            free_pairs.push_back(p);
+        }
+        pairs.clear();
+    }
+    void clear_rows() {
+        rows.clear();
+        index.clear();
+    }
+    ~Profiler() {
+        for (auto& p : pairs) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+        for (auto& p : free_pairs) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    }
+};
+
+ProfScope::ProfScope(Profiler* p_, const char* name, double bytes, double flops, hipStream_t st_)
+    : p(p_), slot(-1), st(st_) {
+    if (p && p->enabled) slot = p->begin(name, bytes, flops, st);
+}
+ProfScope::~ProfScope() {
+    if (p && slot >= 0) p->end(slot, st);
+}
+
+// ------------------------------------------------------------------------------------------------ model
+struct Tensor {
+    const void* ptr = nullptr;
+    std::vector<int64_t> shape;
+};
+struct Lin { const void* w = nullptr; const void* b = nullptr; int out = 0, in = 0; };
+struct NormW { const void* w = nullptr; const void* b = nullptr; };
+struct AttnW { Lin q, k, v, o; };
+struct FfnW { Lin gate, inner, out; };
+struct CtxLayer { NormW sa_norm, ffn_norm; AttnW sa; FfnW ffn; };
+struct DenLayer { NormW sa_norm, ca_norm, ffn_norm; AttnW sa, ca; FfnW ffn; Lin mod; };
+
+}  // namespace lcmhip
+
+struct lcmhip_model {
+    lcmhip_model_desc desc;
+    std::map<std::string, lcmhip::Tensor> tensors;
+    bool finalized = false;
+    const void* center = nullptr;
+    const void* scale = nullptr;
+    lcmhip::Lin pre_linear, t_fc1, t_fc2, init_proj, final_proj;
+    const void* pos_table = nullptr;
+    std::vector<lcmhip::CtxLayer> ctx;
+    std::vector<lcmhip::DenLayer> den;
+    lcmhip::NormW ctx_final, den_final;
+};
+
+namespace lcmhip {
+
+static int get_lin(lcmhip_model* m, const std::string& prefix, int out, int in, bool bias, Lin* l) {
+    auto w = m->tensors.find(prefix + ".weight");
+    if (w == m->tensors.end()) return fail(LCMHIP_ERR_STATE, "missing weight: " + prefix + ".weight");
+    if (w->second.shape.size() != 2 || w->second.shape[0] != out || w->second.shape[1] != in)
+        return fail(LCMHIP_ERR_INVALID, "bad shape for " + prefix + ".weight");
+    l->w = w->second.ptr;
+    l->out = out;
+    l->in = in;
+    l->b = nullptr;
+    if (bias) {
+        auto b = m->tensors.find(prefix + ".bias");
+        if (b == m->tensors.end()) return fail(LCMHIP_ERR_STATE, "missing weight: " + prefix + ".bias");
+        if (b->second.shape.size() != 1 || b->second.shape[0] != out)
+            return fail(LCMHIP_ERR_INVALID, "bad shape for " + prefix + ".bias");
+        l->b = b->second.ptr;
+    }
+    return LCMHIP_OK;
+}
+
+static int get_vec(lcmhip_model* m, const std::string& name, int n, const void** p) {
+    auto t = m->tensors.find(name);
+    if (t == m->tensors.end()) return fail(LCMHIP_ERR_STATE, "missing weight: " + name);
+    if (t->second.shape.size() != 1 || t->second.shape[0] != n) return fail(LCMHIP_ERR_INVALID, "bad shape for " + name);
+    *p = t->second.ptr;
+    return LCMHIP_OK;
+}
+
+static int get_norm(lcmhip_model* m, const std::string& prefix, int d, int kind, NormW* n) {
+    LCM_TRY(get_vec(m, prefix + ".weight", d, &n->w));
+    n->b = nullptr;
+    if (kind == LCMHIP_NORM_LAYERNORM) LCM_TRY(get_vec(m, prefix + ".bias", d, &n->b));
+    return LCMHIP_OK;
+}
+
+static int get_attn(lcmhip_model* m, const std::string& p, int d, bool out_bias, AttnW* a) {
+    LCM_TRY(get_lin(m, p + ".q_proj", d, d, true, &a->q));
+    LCM_TRY(get_lin(m, p + ".k_proj", d, d, true, &a->k));
+    LCM_TRY(get_lin(m, p + ".v_proj", d, d, true, &a->v));
+    LCM_TRY(get_lin(m, p + ".output_proj", d, d, out_bias, &a->o));
+    return LCMHIP_OK;
+}
+
+static int get_ffn(lcmhip_model* m, const std::string& p, int d, const lcmhip_tower_desc& t, FfnW* f) {
+    if (t.ffn_kind == LCMHIP_FFN_SWIGLU) LCM_TRY(get_lin(m, p + ".gate_proj", t.ffn_dim, d, true, &f->gate));
+    LCM_TRY(get_lin(m, p + ".inner_proj", t.ffn_dim, d, true, &f->inner));
+    LCM_TRY(get_lin(m, p + ".output_proj", d, t.ffn_dim, true, &f->out));
+    return LCMHIP_OK;
+}
+
+static int check_tower(const lcmhip_tower_desc& t, int d, const char* which) {
+    LCM_REQUIRE(t.num_layers >= 1, std::string(which) + ": needs at least one layer");
+    LCM_REQUIRE(t.num_heads >= 2 && d == t.num_heads * 128, std::string(which) + ": head_dim must be 128");
+    LCM_REQUIRE(t.num_heads % 4 == 0 || t.num_heads == 2, std::string(which) + ": heads must be 2 or a multiple of 4");
+    LCM_REQUIRE(t.ffn_dim % 128 == 0, std::string(which) + ": ffn_dim must be a multiple of 128");
+    LCM_REQUIRE(t.norm_kind == LCMHIP_NORM_LAYERNORM || t.norm_kind == LCMHIP_NORM_RMS, "unknown norm kind");
+    LCM_REQUIRE(t.ffn_kind == LCMHIP_FFN_RELU || t.ffn_kind == LCMHIP_FFN_SWIGLU, "unknown ffn kind");
+    return LCMHIP_OK;
+}
+
+static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+}  // namespace lcmhip
+
+// ------------------------------------------------------------------------------------------------ session
+struct lcmhip_session {
+    lcmhip_model* model = nullptr;
+    int max_batch = 0, cap = 0, max_steps = 0, rows_cap = 0, chunk_rows = 0;
+    bool keep_context = false;
+    // carved device buffers
+    int32_t *slot_map = nullptr, *pos_rows = nullptr, *self_rows = nullptr, *cross_rows = nullptr, *slot0_rows = nullptr;
+    char *self_k = nullptr, *self_v = nullptr, *cross_k = nullptr, *cross_v = nullptr;
+    float *rope_cos = nullptr, *rope_sin = nullptr;
+    float *mod_table = nullptr, *uconst = nullptr;
+    float *xres = nullptr, *outp = nullptr, *lat = nullptr, *lat2 = nullptr, *x0 = nullptr, *f32tmp = nullptr;
+    char *act_a = nullptr, *act_q = nullptr, *act_k = nullptr, *act_v = nullptr, *act_o = nullptr, *act_h = nullptr,
+         *act_in = nullptr;
+    float* kept_ctx = nullptr;
+    // host state
+    std::vector<int32_t> h_slot;
+    int n_active = 0, ctx_len = 0;
+    bool have_schedule = false;
+    int n_steps = 0;
+    std::vector<int32_t> timesteps;
+    std::vector<lcmhip::DdimScalars> scalars;
+    std::vector<int> step_mode_rows;  // 1: guidance step (2B rows), 0: plain
+    lcmhip_denoise_params params{};
+    bool do_cfg = false;
+    lcmhip::Profiler prof;
+};
+
+namespace lcmhip {
+
+struct Carver {
+    char* base;
+    size_t off = 0;
+    explicit Carver(char* b) : base(b) {}
+    template <typename T>
+    T* take(size_t bytes) {
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += align_up(bytes);
+        return p;
+    }
+};
+
+static bool env_flag(const char* name) {
+    const char* v = getenv(name);
+    return v && v[0] && v[0] != '0';
+}
+
+// Lays out the workspace; with base == nullptr only measures it.
+static size_t carve(lcmhip_session* s, char* base) {
+    const lcmhip_model_desc& d = s->model->desc;
+    const size_t es = dtype_size(d.dtype);
+    const size_t B = s->max_batch, cap = s->cap, dm = d.model_dim, D = d.sonar_dim;
+    const size_t R = s->rows_cap;
+    const size_t F = std::max(d.context.ffn_dim, d.denoiser.ffn_dim);
+    Carver c(base);
+    s->slot_map = c.take<int32_t>(B * 4);
+    s->slot0_rows = c.take<int32_t>(B * 4);
+    s->pos_rows = c.take<int32_t>(R * 4);
+    s->self_rows = c.take<int32_t>(R * 4);
+    s->cross_rows = c.take<int32_t>(R * 4);
+    s->self_k = c.take<char>((size_t)d.context.num_layers * B * cap * dm * es);
+    s->self_v = c.take<char>((size_t)d.context.num_layers * B * cap * dm * es);
+    s->cross_k = c.take<char>((size_t)d.denoiser.num_layers * B * (cap + 1) * dm * es);
+    s->cross_v = c.take<char>((size_t)d.denoiser.num_layers * B * (cap + 1) * dm * es);
+    s->rope_cos = c.take<float>(cap * 64 * 4);
+    s->rope_sin = c.take<float>(cap * 64 * 4);
+    s->mod_table = c.take<float>((size_t)s->max_steps * d.denoiser.num_layers * 9 * dm * 4);
+    s->uconst = c.take<float>((size_t)d.denoiser.num_layers * dm * 4);
+    s->xres = c.take<float>(R * dm * 4);
+    s->f32tmp = c.take<float>(R * std::max(dm, (size_t)d.timestep_freq_dim) * 4);
+    s->outp = c.take<float>(2 * B * D * 4);
+    s->lat = c.take<float>(B * D * 4);
+    s->lat2 = c.take<float>(B * D * 4);
+    s->x0 = c.take<float>(B * D * 4);
+    s->act_in = c.take<char>(R * std::max(D, (size_t)d.timestep_freq_dim) * es);
+    s->act_a = c.take<char>(R * dm * es);
+    s->act_q = c.take<char>(R * dm * es);
+    s->act_k = c.take<char>(R * dm * es);
+    s->act_v = c.take<char>(R * dm * es);
+    s->act_o = c.take<char>(R * dm * es);
+    s->act_h = c.take<char>(R * F * es);
+    s->kept_ctx = s->keep_context ? c.take<float>(B * cap * dm * 4) : nullptr;
+    return c.off;
+}
+
+// ---- tiny index kernels ---------------------------------------------------------------------------
+// Row r = (doc i = r / sc, token jj = r % sc) of an append chunk:
+//   pos[r] = pos0 + jj; self_rows[r] = slot[i] * cap + pos[r]; cross_rows[r] = slot[i] * (cap + 1) + pos[r] + 1
+__global__ void k_make_rows(const int32_t* __restrict__ slot_map, int32_t* pos, int32_t* self_rows,
+                            int32_t* cross_rows, int rows, int sc, int pos0, int cap) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const int i = r / sc, jj = r % sc;
+    const int p = pos0 + jj;
+    const int slot = slot_map[i];
+    pos[r] = p;
+    self_rows[r] = slot * cap + p;
+    cross_rows[r] = slot * (cap + 1) + p + 1;
+}
+
+__global__ void k_slot0_rows(int32_t* slot0_rows, int32_t* slot_map, int n, int cap1) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    slot_map[i] = i;
+    slot0_rows[i] = i * cap1;
+}
+
+// y[r][:] = (x[(i * s_total + j0 + jj)][:] - center) / scale, r = i * sc + jj   (fp32 in, T out)
+template <typename T>
+__global__ __launch_bounds__(128) void k_normalize_gather(const float* __restrict__ x, const T* __restrict__ center,
+                                                          const T* __restrict__ scale, T* __restrict__ y, int D,
+                                                          int sc, int s_total, int j0, int apply) {
+    const int r = blockIdx.x;
+    const int i = r / sc, jj = r % sc;
+    const float* src = x + ((size_t)i * s_total + j0 + jj) * D;
+    T* dst = y + (size_t)r * D;
+    for (int c = threadIdx.x * 8; c < D; c += blockDim.x * 8) {
+        float v[8], ce[8], sv[8];
+        load8<float>(src + c, v);
+        load8<T>(center + c, ce);
+        load8<T>(scale + c, sv);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = apply ? (v[t] - ce[t]) / sv[t] : v[t];
+        store8<T>(dst + c, v);
+    }
+}
+
+// dst[rows_idx-like mapping]: kept_ctx[(slot[i] * cap + pos[r])][:] = src[r][:] as fp32
+template <typename T>
+__global__ __launch_bounds__(256) void k_keep_rows(const T* __restrict__ src, float* __restrict__ dst,
+                                                   const int32_t* __restrict__ rows_idx, int d) {
+    const int r = blockIdx.x;
+    for (int c = threadIdx.x * 8; c < d; c += blockDim.x * 8) {
+        float v[8];
+        load8<T>(src + (size_t)r * d + c, v);
+        store8<float>(dst + (size_t)rows_idx[r] * d + c, v);
+    }
+}
+
+// ---- GEMM helper with profiling ---------------------------------------------------------------------
+static int gemm(lcmhip_session* s, const char* tag, const void* A, int lda, const Lin& W, const Lin* W2,
+                const float* gate, void* out, int ldo, int M, int epi, hipStream_t st,
+                const int32_t* out_rows = nullptr, int extra_rows = 0, const float* extra_const = nullptr) {
+    GemmArgs a{};
+    a.A = A; a.lda = lda;
+    a.W = W.w; a.bias = W.b;
+    a.W2 = W2 ? W2->w : nullptr; a.bias2 = W2 ? W2->b : nullptr;
+    a.gate = gate;
+    a.out = out; a.ldo = ldo; a.out_rows = out_rows;
+    a.M = M; a.N = W.out; a.K = W.in;
+    a.epilogue = epi; a.dtype = s->model->desc.dtype;
+    a.extra_rows = extra_rows; a.extra_const = extra_const;
+    const double es = (double)dtype_size(a.dtype);
+    const double nw = W2 ? 2.0 : 1.0;
+    const double out_es = (epi == LCMHIP_EPI_STORE_F32) ? 4.0 : (epi == LCMHIP_EPI_RESID ? 8.0 : es);
+    const double bytes = nw * a.N * (double)a.K * es + (double)M * a.K * es + (double)(M + extra_rows) * a.N * out_es;
+    const double flops = 2.0 * nw * M * (double)a.N * a.K;
+    ProfScope ps(&s->prof, tag, bytes, flops, st);
+    return launch_gemm(a, st);
+}
+
+static int norm(lcmhip_session* s, const char* tag, const float* x, const NormW& w, const float* shift,
+                const float* scale, void* y, int rows, int kind, hipStream_t st) {
+    const lcmhip_model_desc& d = s->model->desc;
+    const double es = (double)dtype_size(d.dtype);
+    ProfScope ps(&s->prof, tag, rows * (double)d.model_dim * (4.0 + es), 0.0, st);
+    return launch_norm_modulate(x, w.w, w.b, shift, scale, y, rows, d.model_dim, kind, d.norm_eps, d.dtype, st);
+}
+
+static int ffn(lcmhip_session* s, const char* tag_in, const char* tag_out, const lcmhip_tower_desc& t, const FfnW& f,
+               const void* a, const float* gate, float* xres, int rows, int extra_unused, hipStream_t st) {
+    (void)extra_unused;
+    const int d = s->model->desc.model_dim;
+    if (t.ffn_kind == LCMHIP_FFN_SWIGLU)
+        LCM_TRY(gemm(s, tag_in, a, d, f.gate, &f.inner, nullptr, s->act_h, t.ffn_dim, rows, LCMHIP_EPI_SWIGLU, st));
+    else
+        LCM_TRY(gemm(s, tag_in, a, d, f.inner, nullptr, nullptr, s->act_h, t.ffn_dim, rows, LCMHIP_EPI_RELU, st));
+    return gemm(s, tag_out, s->act_h, t.ffn_dim, f.out, nullptr, gate, xres, d, rows, LCMHIP_EPI_RESID, st);
+}
+
+}  // namespace lcmhip
+
+using namespace lcmhip;
+
+// ================================================================================================ C ABI
+extern "C" {
+
+const char* lcmhip_last_error(void) { return g_last_error.c_str(); }
+int lcmhip_version(void) { return 100; }
+
+int lcmhip_model_create(const lcmhip_model_desc* desc, lcmhip_model** out) {
+    LCM_REQUIRE(desc && out, "model_create: null argument");
+    LCM_REQUIRE(desc->dtype == LCMHIP_F32 || desc->dtype == LCMHIP_BF16, "model_create: dtype must be f32 or bf16");
+    LCM_REQUIRE(desc->sonar_dim % 128 == 0 && desc->sonar_dim <= 4096, "model_create: sonar_dim");
+    LCM_REQUIRE(desc->model_dim % 256 == 0 && desc->model_dim <= 8192, "model_create: model_dim");
+    LCM_REQUIRE(desc->timestep_freq_dim % 64 == 0 && desc->timestep_freq_dim > 0, "model_create: timestep_freq_dim");
+    LCM_TRY(check_tower(desc->context, desc->model_dim, "context"));
+    LCM_TRY(check_tower(desc->denoiser, desc->model_dim, "denoiser"));
+    if (desc->denoiser.pos_kind != LCMHIP_POS_NONE)
+        return fail(LCMHIP_ERR_UNSUPPORTED, "denoiser positional encoders are not implemented (reference archs use none)");
+    auto* m = new lcmhip_model();
+    m->desc = *desc;
+    *out = m;
+    return LCMHIP_OK;
+}
+
+int lcmhip_model_bind_weight(lcmhip_model* m, const char* name, const void* ptr, int32_t dtype, int32_t ndim,
+                             const int64_t* shape) {
+    LCM_REQUIRE(m && name && ptr && shape && ndim >= 1 && ndim <= 4, "bind_weight: bad argument");
+    LCM_REQUIRE(dtype == m->desc.dtype, std::string("bind_weight: dtype of ") + name + " differs from the model dtype");
+    LCM_REQUIRE(((uintptr_t)ptr % 16) == 0, std::string("bind_weight: ") + name + " is not 16-byte aligned");
+    Tensor t;
+    t.ptr = ptr;
+    t.shape.assign(shape, shape + ndim);
+    m->tensors[name] = t;
+    m->finalized = false;
+    return LCMHIP_OK;
+}
+
+int lcmhip_model_finalize(lcmhip_model* m) {
+    LCM_REQUIRE(m, "finalize: null model");
+    const lcmhip_model_desc& d = m->desc;
+    const int dm = d.model_dim, D = d.sonar_dim;
+    LCM_TRY(get_vec(m, "sonar_normalizer.center", D, &m->center));
+    LCM_TRY(get_vec(m, "sonar_normalizer.scale", D, &m->scale));
+    LCM_TRY(get_lin(m, "encoder_frontend.pre_linear", dm, D, true, &m->pre_linear));
+    m->pos_table = nullptr;
+    if (d.context.pos_kind == LCMHIP_POS_LEARNED) {
+        auto t = m->tensors.find("encoder_frontend.pos_encoder.weight");
+        if (t == m->tensors.end()) return fail(LCMHIP_ERR_STATE, "missing weight: encoder_frontend.pos_encoder.weight");
+        LCM_REQUIRE(t->second.shape.size() == 2 && t->second.shape[0] >= d.max_seq_len && t->second.shape[1] == dm,
+                    "bad shape for encoder_frontend.pos_encoder.weight");
+        m->pos_table = t->second.ptr;
+    }
+    m->ctx.assign(d.context.num_layers, CtxLayer{});
+    for (int i = 0; i < d.context.num_layers; ++i) {
+        const std::string p = "context_encoder.layers." + std::to_string(i);
+        CtxLayer& L = m->ctx[i];
+        LCM_TRY(get_norm(m, p + ".self_attn_layer_norm", dm, d.context.norm_kind, &L.sa_norm));
+        LCM_TRY(get_norm(m, p + ".ffn_layer_norm", dm, d.context.norm_kind, &L.ffn_norm));
+        LCM_TRY(get_attn(m, p + ".self_attn", dm, d.context.out_proj_bias != 0, &L.sa));
+        LCM_TRY(get_ffn(m, p + ".ffn", dm, d.context, &L.ffn));
+    }
+    LCM_TRY(get_norm(m, "context_encoder.layer_norm", dm, d.context.norm_kind, &m->ctx_final));
+    LCM_TRY(get_lin(m, "denoiser.embed_time.fc1", dm, d.timestep_freq_dim, true, &m->t_fc1));
+    LCM_TRY(get_lin(m, "denoiser.embed_time.fc2", dm, dm, true, &m->t_fc2));
+    LCM_TRY(get_lin(m, "denoiser.initial_proj.fc", dm, D, true, &m->init_proj));
+    LCM_TRY(get_lin(m, "denoiser.final_proj.fc", D, dm, true, &m->final_proj));
+    m->den.assign(d.denoiser.num_layers, DenLayer{});
+    for (int i = 0; i < d.denoiser.num_layers; ++i) {
+        const std::string p = "denoiser.layers." + std::to_string(i);
+        DenLayer& L = m->den[i];
+        LCM_TRY(get_norm(m, p + ".self_attn_layer_norm", dm, d.denoiser.norm_kind, &L.sa_norm));
+        LCM_TRY(get_norm(m, p + ".cross_attention_layer_norm", dm, d.denoiser.norm_kind, &L.ca_norm));
+        LCM_TRY(get_norm(m, p + ".ffn_layer_norm", dm, d.denoiser.norm_kind, &L.ffn_norm));
+        LCM_TRY(get_attn(m, p + ".self_attn", dm, d.denoiser.out_proj_bias != 0, &L.sa));
+        LCM_TRY(get_attn(m, p + ".cross_attention", dm, d.denoiser.out_proj_bias != 0, &L.ca));
+        LCM_TRY(get_ffn(m, p + ".ffn", dm, d.denoiser, &L.ffn));
+        LCM_TRY(get_lin(m, p + ".modulator.fc", 9 * dm, dm, true, &L.mod));
+    }
+    LCM_TRY(get_norm(m, "denoiser.layer_norm", dm, d.denoiser.norm_kind, &m->den_final));
+    m->finalized = true;
+    return LCMHIP_OK;
+}
+
+int lcmhip_model_destroy(lcmhip_model* m) {
+    delete m;
+    return LCMHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ session life cycle
+static int session_dims(lcmhip_session* s, const lcmhip_model* m, int max_batch, int max_ctx, int max_steps) {
+    LCM_REQUIRE(m && m->finalized, "session: model is not finalized");
+    LCM_REQUIRE(max_batch >= 1 && max_batch <= 65536, "session: max_batch");
+    LCM_REQUIRE(max_ctx >= 1 && max_ctx <= m->desc.max_seq_len, "session: max_ctx exceeds the model's max_seq_len");
+    LCM_REQUIRE(max_ctx <= 3800, "session: the attention kernel supports up to 3800 context positions");
+    LCM_REQUIRE(max_steps >= 1 && max_steps <= 4096, "session: max_steps");
+    s->model = const_cast<lcmhip_model*>(m);
+    s->max_batch = max_batch;
+    s->cap = max_ctx;
+    s->max_steps = max_steps;
+    s->chunk_rows = std::max(2 * max_batch, 512);
+    s->rows_cap = std::max(s->chunk_rows, max_steps);
+    s->keep_context = env_flag("LCMHIP_KEEP_CONTEXT");
+    return LCMHIP_OK;
+}
+
+int lcmhip_session_workspace_bytes(const lcmhip_model* m, int32_t max_batch, int32_t max_ctx, int32_t max_steps,
+                                   size_t* bytes) {
+    LCM_REQUIRE(bytes, "workspace_bytes: null output");
+    lcmhip_session tmp;
+    LCM_TRY(session_dims(&tmp, m, max_batch, max_ctx, max_steps));
+    *bytes = carve(&tmp, nullptr);
+    return LCMHIP_OK;
+}
+
+int lcmhip_session_create(lcmhip_model* m, int32_t max_batch, int32_t max_ctx, int32_t max_steps, void* workspace,
+                          size_t bytes, lcmhip_session** out) {
+    LCM_REQUIRE(out && workspace, "session_create: null argument");
+    LCM_REQUIRE(((uintptr_t)workspace % 256) == 0, "session_create: workspace must be 256-byte aligned");
+    auto s = std::make_unique<lcmhip_session>();
+    LCM_TRY(session_dims(s.get(), m, max_batch, max_ctx, max_steps));
+    const size_t need = carve(s.get(), static_cast<char*>(workspace));
+    LCM_REQUIRE(bytes >= need, "session_create: workspace too small");
+    // RoPE angle table, computed the way fairseq2's RotaryEncoder does (fp32 frequencies and angles).
+    if (m->desc.context.pos_kind == LCMHIP_POS_ROPE) {
+        std::vector<float> c((size_t)s->cap * 64), sn((size_t)s->cap * 64);
+        for (int i = 0; i < 64; ++i) {
+            const float freq = 1.0f / powf(m->desc.context.rope_theta, (float)(2 * i) / 128.0f);
+            for (int p = 0; p < s->cap; ++p) {
+                const float ang = (float)p * freq;
+                c[(size_t)p * 64 + i] = (float)cos((double)ang);
+                sn[(size_t)p * 64 + i] = (float)sin((double)ang);
+            }
+        }
+        LCM_HIP_CHECK(hipMemcpy(s->rope_cos, c.data(), c.size() * 4, hipMemcpyHostToDevice));
+        LCM_HIP_CHECK(hipMemcpy(s->rope_sin, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
+    }
+    *out = s.release();
+    return LCMHIP_OK;
+}
+
+int lcmhip_session_destroy(lcmhip_session* s) {
+    delete s;
+    return LCMHIP_OK;
+}
+
+int lcmhip_session_context_len(const lcmhip_session* s) { return s ? s->ctx_len : -1; }
+int lcmhip_session_num_active(const lcmhip_session* s) { return s ? s->n_active : -1; }
+
+int lcmhip_session_reset(lcmhip_session* s, int32_t n_docs, void* stream) {
+    LCM_REQUIRE(s, "reset: null session");
+    LCM_REQUIRE(n_docs >= 1 && n_docs <= s->max_batch, "reset: n_docs exceeds the session's max_batch");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const lcmhip_model* m = s->model;
+    const lcmhip_model_desc& d = m->desc;
+    s->n_active = n_docs;
+    s->ctx_len = 0;
+    s->h_slot.resize(n_docs);
+    for (int i = 0; i < n_docs; ++i) s->h_slot[i] = i;
+    hipLaunchKernelGGL(k_slot0_rows, dim3((n_docs + 255) / 256), dim3(256), 0, st, s->slot0_rows, s->slot_map, n_docs,
+                       s->cap + 1);
+    LCM_HIP_CHECK(hipGetLastError());
+    // Cross-attention key/value of the prepended zero vector = the k_proj / v_proj biases
+    // (lcm_denoiser.py:193-199): position 0 of every document, every layer.
+    const size_t es = dtype_size(d.dtype);
+    const size_t layer_bytes = (size_t)s->max_batch * (s->cap + 1) * d.model_dim * es;
+    for (int l = 0; l < d.denoiser.num_layers; ++l) {
+        LCM_TRY(launch_fill_rows(s->cross_k + l * layer_bytes, m->den[l].ca.k.b, s->slot0_rows, n_docs, d.model_dim,
+                                 d.dtype, st));
+        LCM_TRY(launch_fill_rows(s->cross_v + l * layer_bytes, m->den[l].ca.v.b, s->slot0_rows, n_docs, d.model_dim,
+                                 d.dtype, st));
+    }
+    return LCMHIP_OK;
+}
+
+int lcmhip_session_reorder(lcmhip_session* s, const int32_t* order, int32_t n, void* stream) {
+    LCM_REQUIRE(s && order, "reorder: null argument");
+    LCM_REQUIRE(n >= 1 && n <= s->n_active, "reorder: bad row count");
+    std::vector<int32_t> ns(n);
+    for (int i = 0; i < n; ++i) {
+        LCM_REQUIRE(order[i] >= 0 && order[i] < s->n_active, "reorder: index out of range");
+        LCM_REQUIRE(i == 0 || order[i] > order[i - 1], "reorder: indices must be strictly increasing");
+        ns[i] = s->h_slot[order[i]];
+    }
+    s->h_slot = ns;
+    s->n_active = n;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // pageable source: the runtime stages the copy before returning, so `ns` may go out of scope
+    LCM_HIP_CHECK(hipMemcpyAsync(s->slot_map, s->h_slot.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    return LCMHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ schedule
+int lcmhip_session_set_schedule(lcmhip_session* s, const int32_t* timesteps, int32_t n_steps,
+                                const float* alphas_cumprod, int32_t num_train_steps, float final_alpha_cumprod,
+                                int32_t step_ratio, const lcmhip_denoise_params* params, void* stream) {
+    LCM_REQUIRE(s && timesteps && alphas_cumprod && params, "set_schedule: null argument");
+    LCM_REQUIRE(n_steps >= 1 && n_steps <= s->max_steps, "set_schedule: more steps than the session was sized for");
+    if (params->ddim_eta != 0.f)
+        return fail(LCMHIP_ERR_UNSUPPORTED, "ddim_eta != 0 (stochastic DDIM) is not implemented");
+    LCM_REQUIRE(params->prediction_type >= 0 && params->prediction_type <= 2, "set_schedule: prediction_type");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    lcmhip_model* m = s->model;
+    const lcmhip_model_desc& d = m->desc;
+    const int dm = d.model_dim, FD = d.timestep_freq_dim, L = d.denoiser.num_layers;
+    s->params = *params;
+    s->do_cfg = params->guidance_scale != 1.0f;
+    s->n_steps = n_steps;
+    s->timesteps.assign(timesteps, timesteps + n_steps);
+    s->scalars.assign(n_steps, DdimScalars{});
+    s->step_mode_rows.assign(n_steps, 0);
+    for (int i = 0; i < n_steps; ++i) {
+        const int t = timesteps[i];
+        LCM_REQUIRE(t >= 0 && t < num_train_steps, "set_schedule: timestep out of range");
+        const int prev = t - step_ratio;                                   // ddim.py:421-423
+        const float a_t = alphas_cumprod[t];
+        const float a_prev = prev >= 0 ? alphas_cumprod[prev] : final_alpha_cumprod;   // ddim.py:426-431
+        const float b_t = 1.0f - a_t;
+        DdimScalars& sc = s->scalars[i];
+        sc.sqrt_a_t = sqrtf(a_t);
+        sc.sqrt_b_t = sqrtf(b_t);
+        sc.sqrt_a_prev = sqrtf(a_prev);
+        sc.dir_coef = sqrtf(1.0f - a_prev);                                // eta = 0: sigma_t = 0 (ddim.py:473-485)
+        sc.guidance_scale = params->guidance_scale;
+        sc.guidance_rescale = params->guidance_rescale;
+        sc.inv_eps_scaling = params->epsilon_scaling > 0.f ? 1.0f / params->epsilon_scaling : 1.0f;
+        sc.clip_noise = params->clip_noise;
+        sc.clip_sample_range = params->clip_sample ? params->clip_sample_range : -1.0f;
+        sc.prediction_type = params->prediction_type;
+        // builder.py:385-387, 404-449: no guidance on the step whose timestep is T - 1
+        const bool is_max = (t == num_train_steps - 1);
+        sc.mode = (s->do_cfg && !is_max) ? 1 : 0;
+        s->step_mode_rows[i] = sc.mode;
+    }
+    // ---- timestep embeddings -> adaLN table (timestep_encoder.py:72-122, lcm_denoiser.py:60-64)
+    std::vector<float> tf((size_t)n_steps * FD);
+    const int half = FD / 2;
+    for (int i = 0; i < n_steps; ++i)
+        for (int k = 0; k < half; ++k) {
+            const float freq = expf(-logf(10000.0f) * (float)k / (float)half);
+            const float arg = (float)timesteps[i] * freq;
+            tf[(size_t)i * FD + k] = (float)cos((double)arg);
+            tf[(size_t)i * FD + half + k] = (float)sin((double)arg);
+        }
+    LCM_HIP_CHECK(hipMemcpyAsync(s->f32tmp, tf.data(), tf.size() * 4, hipMemcpyHostToDevice, st));
+    LCM_TRY(launch_cast(s->f32tmp, s->act_in, (int64_t)n_steps * FD, d.dtype, st));
+    LCM_TRY(gemm(s, "setup", s->act_in, FD, m->t_fc1, nullptr, nullptr, s->f32tmp, dm, n_steps, LCMHIP_EPI_STORE_F32, st));
+    LCM_TRY(launch_silu_cast(s->f32tmp, s->act_a, (int64_t)n_steps * dm, d.dtype, st));
+    LCM_TRY(gemm(s, "setup", s->act_a, dm, m->t_fc2, nullptr, nullptr, s->f32tmp, dm, n_steps, LCMHIP_EPI_STORE_F32, st));
+    // the reference keeps the embedding in the model dtype before the modulator's SiLU
+    LCM_TRY(launch_cast(s->f32tmp, s->act_q, (int64_t)n_steps * dm, d.dtype, st));
+    LCM_TRY(launch_copy_rows_to_f32(s->act_q, s->f32tmp, (int64_t)n_steps * dm, d.dtype, st));
+    LCM_TRY(launch_silu_cast(s->f32tmp, s->act_a, (int64_t)n_steps * dm, d.dtype, st));
+    for (int l = 0; l < L; ++l)
+        LCM_TRY(gemm(s, "setup", s->act_a, dm, m->den[l].mod, nullptr, nullptr, s->mod_table + (size_t)l * 9 * dm,
+                     L * 9 * dm, n_steps, LCMHIP_EPI_STORE_F32, st));
+    // ---- unconditional rows: cross-attention output = output_proj(v_proj(0)) = W_o b_v + b_o
+    for (int l = 0; l < L; ++l)
+        LCM_TRY(gemm(s, "setup", m->den[l].ca.v.b, dm, m->den[l].ca.o, nullptr, nullptr, s->uconst + (size_t)l * dm, dm,
+                     1, LCMHIP_EPI_STORE_F32, st));
+    LCM_HIP_CHECK(hipStreamSynchronize(st));
+    s->have_schedule = true;
+    return LCMHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ contextualizer
+int lcmhip_context_append(lcmhip_session* s, const float* x, int32_t n_tokens, int32_t normalized, void* stream) {
+    LCM_REQUIRE(s && x, "context_append: null argument");
+    LCM_REQUIRE(s->n_active >= 1, "context_append: call session_reset first");
+    LCM_REQUIRE(n_tokens >= 1 && s->ctx_len + n_tokens <= s->cap, "context_append: context exceeds the session's max_ctx");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    lcmhip_model* m = s->model;
+    const lcmhip_model_desc& d = m->desc;
+    const lcmhip_tower_desc& tc = d.context;
+    const int dm = d.model_dim, D = d.sonar_dim, n = s->n_active;
+    const size_t es = dtype_size(d.dtype);
+    const size_t self_layer = (size_t)s->max_batch * s->cap * dm * es;
+    const size_t cross_layer = (size_t)s->max_batch * (s->cap + 1) * dm * es;
+    const int per_chunk = std::max(1, s->chunk_rows / n);
+
+    for (int j0 = 0; j0 < n_tokens; j0 += per_chunk) {
+        const int sc = std::min(per_chunk, n_tokens - j0);
+        const int R = n * sc;
+        const int pos0 = s->ctx_len + j0;
+        hipLaunchKernelGGL(k_make_rows, dim3((R + 255) / 256), dim3(256), 0, st, s->slot_map, s->pos_rows, s->self_rows,
+                           s->cross_rows, R, sc, pos0, s->cap);
+        LCM_HIP_CHECK(hipGetLastError());
+        {
+            ProfScope ps(&s->prof, "ctx.normalize", R * (double)D * (4.0 + es), 0.0, st);
+            if (d.dtype == LCMHIP_BF16)
+                hipLaunchKernelGGL((k_normalize_gather<bf16_t>), dim3(R), dim3(128), 0, st, x, (const bf16_t*)m->center,
+                                   (const bf16_t*)m->scale, (bf16_t*)s->act_in, D, sc, n_tokens, j0, normalized ? 0 : 1);
+            else
+                hipLaunchKernelGGL((k_normalize_gather<float>), dim3(R), dim3(128), 0, st, x, (const float*)m->center,
+                                   (const float*)m->scale, (float*)s->act_in, D, sc, n_tokens, j0, normalized ? 0 : 1);
+            LCM_HIP_CHECK(hipGetLastError());
+        }
+        LCM_TRY(gemm(s, "ctx.frontend", s->act_in, D, m->pre_linear, nullptr, nullptr, s->xres, dm, R, LCMHIP_EPI_STORE_F32, st));
+        if (tc.pos_kind == LCMHIP_POS_LEARNED) LCM_TRY(launch_add_pos(s->xres, m->pos_table, s->pos_rows, R, dm, d.dtype, st));
+        for (int l = 0; l < tc.num_layers; ++l) {
+            const CtxLayer& L = m->ctx[l];
+            LCM_TRY(norm(s, "ctx.norm", s->xres, L.sa_norm, nullptr, nullptr, s->act_a, R, tc.norm_kind, st));
+            LCM_TRY(gemm(s, "ctx.qkv", s->act_a, dm, L.sa.q, nullptr, nullptr, s->act_q, dm, R, LCMHIP_EPI_STORE, st));
+            LCM_TRY(gemm(s, "ctx.qkv", s->act_a, dm, L.sa.k, nullptr, nullptr, s->act_k, dm, R, LCMHIP_EPI_STORE, st));
+            LCM_TRY(gemm(s, "ctx.qkv", s->act_a, dm, L.sa.v, nullptr, nullptr, s->act_v, dm, R, LCMHIP_EPI_STORE, st));
+            {
+                ProfScope ps(&s->prof, "ctx.rope_store", 5.0 * R * dm * es, 0.0, st);
+                LCM_TRY(launch_rope_store(s->act_q, s->act_k, s->act_v, s->self_k + l * self_layer, s->self_v + l * self_layer,
+                                          s->self_rows, s->pos_rows, s->rope_cos, s->rope_sin, R, dm,
+                                          tc.pos_kind == LCMHIP_POS_ROPE, d.dtype, st));
+            }
+            {
+                ProfScope ps(&s->prof, "ctx.attn", 2.0 * n * (double)(pos0 + sc) * dm * es, 4.0 * R * (double)(pos0 + sc) * dm, st);
+                LCM_TRY(launch_attention(s->act_q, s->self_k + l * self_layer, s->self_v + l * self_layer, s->slot_map, s->act_o,
+                                         n, sc, tc.num_heads, s->cap, pos0, 1, d.dtype, st));
+            }
+            LCM_TRY(gemm(s, "ctx.attn_out", s->act_o, dm, L.sa.o, nullptr, nullptr, s->xres, dm, R, LCMHIP_EPI_RESID, st));
+            LCM_TRY(norm(s, "ctx.norm", s->xres, L.ffn_norm, nullptr, nullptr, s->act_a, R, tc.norm_kind, st));
+            LCM_TRY(ffn(s, "ctx.ffn_in", "ctx.ffn_out", tc, L.ffn, s->act_a, nullptr, s->xres, R, 0, st));
+        }
+        LCM_TRY(norm(s, "ctx.norm", s->xres, m->ctx_final, nullptr, nullptr, s->act_a, R, tc.norm_kind, st));
+        // cross-attention keys / values of the new context positions, every denoiser layer
+        for (int l = 0; l < d.denoiser.num_layers; ++l) {
+            LCM_TRY(gemm(s, "ctx.cross_kv", s->act_a, dm, m->den[l].ca.k, nullptr, nullptr, s->cross_k + l * cross_layer, dm, R,
+                         LCMHIP_EPI_STORE, st, s->cross_rows));
+            LCM_TRY(gemm(s, "ctx.cross_kv", s->act_a, dm, m->den[l].ca.v, nullptr, nullptr, s->cross_v + l * cross_layer, dm, R,
+                         LCMHIP_EPI_STORE, st, s->cross_rows));
+        }
+        if (s->keep_context) {
+            if (d.dtype == LCMHIP_BF16)
+                hipLaunchKernelGGL((k_keep_rows<bf16_t>), dim3(R), dim3(256), 0, st, (const bf16_t*)s->act_a, s->kept_ctx, s->self_rows, dm);
+            else
+                hipLaunchKernelGGL((k_keep_rows<float>), dim3(R), dim3(256), 0, st, (const float*)s->act_a, s->kept_ctx, s->self_rows, dm);
+            LCM_HIP_CHECK(hipGetLastError());
+        }
+    }
+    s->ctx_len += n_tokens;
+    return LCMHIP_OK;
+}
+
+int lcmhip_session_read_context(lcmhip_session* s, int32_t row, float* out, void* stream) {
+    LCM_REQUIRE(s && out, "read_context: null argument");
+    if (!s->keep_context) return fail(LCMHIP_ERR_STATE, "read_context: session was created without LCMHIP_KEEP_CONTEXT=1");
+    LCM_REQUIRE(row >= 0 && row < s->n_active, "read_context: row out of range");
+    const size_t dm = s->model->desc.model_dim;
+    LCM_HIP_CHECK(hipMemcpyAsync(out, s->kept_ctx + (size_t)s->h_slot[row] * s->cap * dm, (size_t)s->ctx_len * dm * 4,
+                                 hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+    return LCMHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ denoising loop
+int lcmhip_denoise(lcmhip_session* s, const float* noise, float* out, float* latents_trace, void* stream) {
+    LCM_REQUIRE(s && noise && out, "denoise: null argument");
+    if (!s->have_schedule) return fail(LCMHIP_ERR_STATE, "denoise: call session_set_schedule first");
+    LCM_REQUIRE(s->n_active >= 1 && s->ctx_len >= 1, "denoise: empty context (append at least one position first)");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    lcmhip_model* m = s->model;
+    const lcmhip_model_desc& d = m->desc;
+    const lcmhip_tower_desc& td = d.denoiser;
+    const int dm = d.model_dim, D = d.sonar_dim, B = s->n_active, L = td.num_layers;
+    const size_t es = dtype_size(d.dtype);
+    const size_t cross_layer = (size_t)s->max_batch * (s->cap + 1) * dm * es;
+    const int nkeys = s->ctx_len + 1;
+
+    LCM_TRY(launch_init_latents(noise, s->lat, (int64_t)B * D, s->params.init_noise_sigma, s->params.clip_noise, st));
+    float* lat = s->lat;
+    float* lat_next = s->lat2;
+    for (int si = 0; si < s->n_steps; ++si) {
+        const DdimScalars& sc = s->scalars[si];
+        const int rows = sc.mode == 1 ? 2 * B : B;
+        const float* mod_step = s->mod_table + (size_t)si * L * 9 * dm;
+        // initial projection: both halves of the doubled batch see the same latents
+        LCM_TRY(launch_cast(lat, s->act_in, (int64_t)B * D, d.dtype, st));
+        LCM_TRY(gemm(s, "den.initial_proj", s->act_in, D, m->init_proj, nullptr, nullptr, s->xres, dm, B, LCMHIP_EPI_STORE_F32, st));
+        if (rows == 2 * B) LCM_HIP_CHECK(hipMemcpyAsync(s->xres + (size_t)B * dm, s->xres, (size_t)B * dm * 4, hipMemcpyDeviceToDevice, st));
+        for (int l = 0; l < L; ++l) {
+            const DenLayer& Ly = m->den[l];
+            const float* mod = mod_step + (size_t)l * 9 * dm;
+            // self-attention over a single position: softmax == 1, so the block is output_proj(v_proj(h))
+            LCM_TRY(norm(s, "den.norm_mod", s->xres, Ly.sa_norm, mod, mod + dm, s->act_a, rows, td.norm_kind, st));
+            LCM_TRY(gemm(s, "den.self_v", s->act_a, dm, Ly.sa.v, nullptr, nullptr, s->act_v, dm, rows, LCMHIP_EPI_STORE, st));
+            LCM_TRY(gemm(s, "den.self_o", s->act_v, dm, Ly.sa.o, nullptr, mod + 2 * dm, s->xres, dm, rows, LCMHIP_EPI_RESID, st));
+            // cross-attention: conditional rows attend to [zero slot, context]; unconditional rows only
+            // see the zero slot, whose value is a per-layer constant
+            LCM_TRY(norm(s, "den.norm_mod", s->xres, Ly.ca_norm, mod + 3 * dm, mod + 4 * dm, s->act_a, B, td.norm_kind, st));
+            LCM_TRY(gemm(s, "den.cross_q", s->act_a, dm, Ly.ca.q, nullptr, nullptr, s->act_q, dm, B, LCMHIP_EPI_STORE, st));
+            {
+                ProfScope ps(&s->prof, "den.cross_attn", 2.0 * B * (double)nkeys * dm * es + 2.0 * B * dm * es,
+                             4.0 * B * (double)nkeys * dm, st);
+                LCM_TRY(launch_attention(s->act_q, s->cross_k + l * cross_layer, s->cross_v + l * cross_layer, s->slot_map,
+                                         s->act_o, B, 1, td.num_heads, s->cap + 1, nkeys, 0, d.dtype, st));
+            }
+            LCM_TRY(gemm(s, "den.cross_o", s->act_o, dm, Ly.ca.o, nullptr, mod + 5 * dm, s->xres, dm, B, LCMHIP_EPI_RESID, st,
+                         nullptr, rows - B, s->uconst + (size_t)l * dm));
+            LCM_TRY(norm(s, "den.norm_mod", s->xres, Ly.ffn_norm, mod + 6 * dm, mod + 7 * dm, s->act_a, rows, td.norm_kind, st));
+            LCM_TRY(ffn(s, "den.ffn_in", "den.ffn_out", td, Ly.ffn, s->act_a, mod + 8 * dm, s->xres, rows, 0, st));
+        }
+        LCM_TRY(norm(s, "den.norm_mod", s->xres, m->den_final, nullptr, nullptr, s->act_a, rows, td.norm_kind, st));
+        LCM_TRY(gemm(s, "den.final_proj", s->act_a, dm, m->final_proj, nullptr, nullptr, s->outp, D, rows, LCMHIP_EPI_STORE_F32, st));
+        {
+            ProfScope ps(&s->prof, "den.ddim_cfg_step", (double)B * D * 4.0 * (rows == 2 * B ? 5.0 : 4.0), 0.0, st);
+            LCM_TRY(launch_ddim_step(lat, s->outp, rows == 2 * B ? s->outp + (size_t)B * D : nullptr, lat_next, s->x0, B, D, sc, st));
+        }
+        std::swap(lat, lat_next);
+        if (latents_trace)
+            LCM_HIP_CHECK(hipMemcpyAsync(latents_trace + (size_t)si * B * D, lat, (size_t)B * D * 4, hipMemcpyDeviceToDevice, st));
+    }
+    return launch_denormalize_f32_out(s->x0, m->center, m->scale, out, B, D, d.dtype, st);
+}
+
+// ------------------------------------------------------------------------------------------------ profiling
+int lcmhip_session_profile_enable(lcmhip_session* s, int32_t on) {
+    LCM_REQUIRE(s, "profile_enable: null session");
+    s->prof.enabled = on != 0;
+    return LCMHIP_OK;
+}
+
+int lcmhip_session_profile(lcmhip_session* s, lcmhip_profile_row* rows, int32_t max_rows, int32_t* n_rows, void* stream) {
+    LCM_REQUIRE(s && rows && n_rows, "profile: null argument");
+    LCM_HIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    s->prof.collect();
+    int n = 0;
+    for (const auto& r : s->prof.rows) {
+        if (n >= max_rows) break;
+        lcmhip_profile_row& o = rows[n++];
+        memset(&o, 0, sizeof(o));
+        strncpy(o.name, r.name.c_str(), sizeof(o.name) - 1);
+        o.launches = r.launches;
+        o.total_ms = r.ms;
+        o.bytes = r.bytes;
+        o.flops = r.flops;
+    }
+    *n_rows = n;
+    s->prof.clear_rows();
+    return LCMHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ single kernels
+int lcmhip_normalize(const void* x, const void* center, const void* scale, const void* clip_min, const void* clip_max,
+                     void* y, int64_t rows, int32_t dim, int32_t dtype, void* stream) {
+    LCM_REQUIRE(x && center && scale && y, "normalize: null argument");
+    return launch_normalize(x, center, scale, clip_min, clip_max, y, rows, dim, dtype, false, static_cast<hipStream_t>(stream));
+}
+
+int lcmhip_denormalize(const void* x, const void* center, const void* scale, const void* clip_min, const void* clip_max,
+                       void* y, int64_t rows, int32_t dim, int32_t dtype, void* stream) {
+    LCM_REQUIRE(x && center && scale && y, "denormalize: null argument");
+    return launch_normalize(x, center, scale, clip_min, clip_max, y, rows, dim, dtype, true, static_cast<hipStream_t>(stream));
+}
+
+int lcmhip_norm_modulate(const float* x, const void* weight, const void* bias, const float* shift, const float* scale,
+                         void* y, int32_t rows, int32_t dim, int32_t norm_kind, float eps, int32_t dtype, void* stream) {
+    LCM_REQUIRE(x && y, "norm_modulate: null argument");
+    LCM_REQUIRE(norm_kind == LCMHIP_NORM_RMS || norm_kind == LCMHIP_NORM_LAYERNORM, "norm_modulate: unknown norm kind");
+    return launch_norm_modulate(x, weight, bias, shift, scale, y, rows, dim, norm_kind, eps, dtype, static_cast<hipStream_t>(stream));
+}
+
+int lcmhip_gemm(const void* A, int32_t lda, const void* W, const void* W2, const void* bias, const void* bias2,
+                const float* gate, void* out, int32_t ldo, int32_t M, int32_t N, int32_t K, int32_t epilogue,
+                int32_t dtype, void* stream) {
+    LCM_REQUIRE(A && W && out, "gemm: null argument");
+    GemmArgs a{};
+    a.A = A; a.lda = lda; a.W = W; a.W2 = W2; a.bias = bias; a.bias2 = bias2; a.gate = gate;
+    a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.epilogue = epilogue; a.dtype = dtype;
+    return launch_gemm(a, static_cast<hipStream_t>(stream));
+}
+
+int lcmhip_ddim_cfg_step(const float* sample, const float* out_cond, const float* out_uncond, float* prev_sample,
+                         float* pred_x0, int32_t rows, int32_t dim, float alpha_prod_t, float alpha_prod_t_prev,
+                         const lcmhip_denoise_params* p, void* stream) {
+    LCM_REQUIRE(sample && out_cond && prev_sample && pred_x0 && p, "ddim_cfg_step: null argument");
+    if (p->ddim_eta != 0.f) return fail(LCMHIP_ERR_UNSUPPORTED, "ddim_eta != 0 (stochastic DDIM) is not implemented");
+    DdimScalars sc{};
+    sc.sqrt_a_t = sqrtf(alpha_prod_t);
+    sc.sqrt_b_t = sqrtf(1.0f - alpha_prod_t);
+    sc.sqrt_a_prev = sqrtf(alpha_prod_t_prev);
+    sc.dir_coef = sqrtf(1.0f - alpha_prod_t_prev);
+    sc.guidance_scale = p->guidance_scale;
+    sc.guidance_rescale = p->guidance_rescale;
+    sc.inv_eps_scaling = p->epsilon_scaling > 0.f ? 1.0f / p->epsilon_scaling : 1.0f;
+    sc.clip_noise = p->clip_noise;
+    sc.clip_sample_range = p->clip_sample ? p->clip_sample_range : -1.0f;
+    sc.prediction_type = p->prediction_type;
+    sc.mode = out_uncond ? 1 : 0;
+    return launch_ddim_step(sample, out_cond, out_uncond, prev_sample, pred_x0, rows, dim, sc, static_cast<hipStream_t>(stream));
+}
+
+int lcmhip_attention(const void* q, const void* k_cache, const void* v_cache, const int32_t* slot_map, void* out,
+                     int32_t n_docs, int32_t s, int32_t n_heads, int32_t cap, int32_t base_keys, int32_t causal,
+                     int32_t dtype, void* stream) {
+    LCM_REQUIRE(q && k_cache && v_cache && out, "attention: null argument");
+    return launch_attention(q, k_cache, v_cache, slot_map, out, n_docs, s, n_heads, cap, base_keys, causal, dtype,
+                            static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,132 @@
+"""ctypes binding of liblcm_hip.so (the C ABI declared in include/lcmhip.h).
+
+The library is built in-tree by `__graft_entry__.build()` / `make -C chimera-llm_amd/csrc`.
+There is no CPU fallback: importing this module without the library raises.
+"""
+
+import ctypes as C
+import os
+from typing import List, Tuple
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblcm_hip.so")
+
+F32, BF16 = 0, 1
+NORM_LAYERNORM, NORM_RMS = 0, 1
+FFN_RELU, FFN_SWIGLU = 0, 1
+POS_NONE, POS_LEARNED, POS_ROPE = 0, 1, 2
+PRED = {"sample": 0, "epsilon": 1, "v_prediction": 2}
+EPI_STORE, EPI_STORE_F32, EPI_RELU, EPI_SWIGLU, EPI_RESID = 0, 1, 2, 3, 4
+
+EXPORTS = [
+    "lcmhip_last_error", "lcmhip_version",
+    "lcmhip_model_create", "lcmhip_model_bind_weight", "lcmhip_model_finalize", "lcmhip_model_destroy",
+    "lcmhip_session_workspace_bytes", "lcmhip_session_create", "lcmhip_session_destroy",
+    "lcmhip_session_set_schedule", "lcmhip_session_reset", "lcmhip_context_append", "lcmhip_denoise",
+    "lcmhip_session_reorder", "lcmhip_session_context_len", "lcmhip_session_num_active",
+    "lcmhip_session_read_context", "lcmhip_session_profile_enable", "lcmhip_session_profile",
+    "lcmhip_normalize", "lcmhip_denormalize", "lcmhip_norm_modulate", "lcmhip_gemm",
+    "lcmhip_ddim_cfg_step", "lcmhip_attention",
+]
+
+
+class TowerDesc(C.Structure):
+    _fields_ = [("num_layers", C.c_int32), ("num_heads", C.c_int32), ("ffn_dim", C.c_int32),
+                ("norm_kind", C.c_int32), ("ffn_kind", C.c_int32), ("pos_kind", C.c_int32),
+                ("out_proj_bias", C.c_int32), ("rope_theta", C.c_float)]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("sonar_dim", C.c_int32), ("model_dim", C.c_int32), ("max_seq_len", C.c_int32),
+                ("timestep_freq_dim", C.c_int32), ("dtype", C.c_int32), ("norm_eps", C.c_float),
+                ("context", TowerDesc), ("denoiser", TowerDesc)]
+
+
+class DenoiseParams(C.Structure):
+    _fields_ = [("guidance_scale", C.c_float), ("guidance_rescale", C.c_float), ("ddim_eta", C.c_float),
+                ("epsilon_scaling", C.c_float), ("clip_noise", C.c_float), ("init_noise_sigma", C.c_float),
+                ("prediction_type", C.c_int32), ("clip_sample", C.c_int32), ("clip_sample_range", C.c_float)]
+
+
+class ProfileRow(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double),
+                ("bytes", C.c_double), ("flops", C.c_double)]
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C chimera-llm_amd/csrc`). The lcm package has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    lib.lcmhip_last_error.restype = C.c_char_p
+    lib.lcmhip_last_error.argtypes = []
+    lib.lcmhip_version.restype = C.c_int
+    sig = {
+        "lcmhip_model_create": [C.POINTER(ModelDesc), C.POINTER(vp)],
+        "lcmhip_model_bind_weight": [vp, C.c_char_p, vp, i32, i32, C.POINTER(i64)],
+        "lcmhip_model_finalize": [vp],
+        "lcmhip_model_destroy": [vp],
+        "lcmhip_session_workspace_bytes": [vp, i32, i32, i32, C.POINTER(C.c_size_t)],
+        "lcmhip_session_create": [vp, i32, i32, i32, vp, C.c_size_t, C.POINTER(vp)],
+        "lcmhip_session_destroy": [vp],
+        "lcmhip_session_set_schedule": [vp, C.POINTER(i32), i32, C.POINTER(f32), i32, f32, i32,
+                                        C.POINTER(DenoiseParams), vp],
+        "lcmhip_session_reset": [vp, i32, vp],
+        "lcmhip_context_append": [vp, vp, i32, i32, vp],
+        "lcmhip_denoise": [vp, vp, vp, vp, vp],
+        "lcmhip_session_reorder": [vp, C.POINTER(i32), i32, vp],
+        "lcmhip_session_context_len": [vp],
+        "lcmhip_session_num_active": [vp],
+        "lcmhip_session_read_context": [vp, i32, vp, vp],
+        "lcmhip_session_profile_enable": [vp, i32],
+        "lcmhip_session_profile": [vp, C.POINTER(ProfileRow), i32, C.POINTER(i32), vp],
+        "lcmhip_normalize": [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp],
+        "lcmhip_denormalize": [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp],
+        "lcmhip_norm_modulate": [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp],
+        "lcmhip_gemm": [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+        "lcmhip_ddim_cfg_step": [vp, vp, vp, vp, vp, i32, i32, f32, f32, C.POINTER(DenoiseParams), vp],
+        "lcmhip_attention": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    }
+    for name, argtypes in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = lib.lcmhip_last_error()
+        raise RuntimeError(f"lcmhip error {rc}: {msg.decode() if msg else '?'}")
+
+
+def dtype_code(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.bfloat16:
+        return BF16
+    raise ValueError(f"the HIP path supports float32 and bfloat16 weights, got {dtype}")
+
+
+def ptr(t) -> C.c_void_p:
+    """Device pointer of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return C.c_void_p(0)
+    assert t.is_contiguous(), "lcmhip needs contiguous tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_gpu(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{what} must live on a GPU: the lcm package runs only on the HIP path")

@@ -1,0 +1,439 @@
+"""Two-tower diffusion LCM whose arithmetic runs in liblcm_hip.so.
+
+Public surface kept from the reference's lcm/models/two_tower_diffusion_lcm/builder.py:
+`TwoTowerDiffusionLCModelConfig` (:49-81), the `lcm_archs` registry (:84-85),
+`TwoTowerDiffusionLCModel.{encode, prep_for_denoising, predict_next_sentence,
+predict_next_sentence_with_cf_guidance}` (:161-191, 215-242, 262-461) and
+`create_two_tower_diffusion_lcm_model` (:610-628).  Parameters are plain device tensors named
+like the reference's state dict; a `DeviceSession` owns the KV caches and scratch of one batch.
+"""
+
+import ctypes as C
+import logging
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from lcm import _hip
+from lcm.datasets.batch import EmbeddingsBatch
+from lcm.models.abstract_lcm import AbstractLCModel, AbstractLCModelConfig
+from lcm.models.sonar_normalizer.builder import SonarNormalizer, SonarNormalizerConfig
+from lcm.nn.incremental_state import LCMIncrementalStateBag
+from lcm.nn.schedulers import DDIMScheduler, DDIMSchedulerConfig
+from lcm.nn.transformer_config import DenoiserConfig, EncoderFrontendConfig, TransformerConfig
+
+logger = logging.getLogger(__name__)
+
+TWO_TOWER_DIFFUSION_LCM_MODEL_TYPE = "two_tower_diffusion_lcm"
+
+
+@dataclass
+class TwoTowerDiffusionLCModelConfig(AbstractLCModelConfig):
+    model_type: str = TWO_TOWER_DIFFUSION_LCM_MODEL_TYPE
+    max_seq_len: int = 2048
+    model_dim: int = 1024
+    frontend: EncoderFrontendConfig = field(default_factory=EncoderFrontendConfig)
+    context_encoder: TransformerConfig = field(default_factory=TransformerConfig)
+    noise_scheduler: DDIMSchedulerConfig = field(default_factory=DDIMSchedulerConfig)
+    denoiser: DenoiserConfig = field(default_factory=DenoiserConfig)
+    trained_with_cf_guidance: bool = False
+
+
+class _ArchRegistry(dict):
+    def decorator(self, name: str) -> Callable:
+        def register(fn):
+            self[name] = fn
+            return fn
+        return register
+
+    def get_config(self, name: str) -> TwoTowerDiffusionLCModelConfig:
+        if name not in self:
+            raise KeyError(f"unknown two_tower_diffusion_lcm architecture '{name}' (known: {sorted(self)})")
+        return self[name]()
+
+
+lcm_archs = _ArchRegistry()
+lcm_arch = lcm_archs.decorator
+
+_NORM_KIND = {"standard": _hip.NORM_LAYERNORM, "rms": _hip.NORM_RMS}
+_POS_KIND = {"none": _hip.POS_NONE, "learned": _hip.POS_LEARNED, "rope": _hip.POS_ROPE}
+TIMESTEP_FREQ_DIM = 256
+
+
+def _check_supported(name: str, tc: TransformerConfig) -> None:
+    bad = []
+    if tc.layer_normalization_style not in _NORM_KIND:
+        bad.append(f"layer_normalization_style={tc.layer_normalization_style}")
+    if tc.norm_order_style != "pre" or tc.final_norm_order_style not in (None, "pre"):
+        bad.append("only pre-norm stacks")
+    if tc.pos_embedding_style not in _POS_KIND:
+        bad.append(f"pos_embedding_style={tc.pos_embedding_style}")
+    if tc.enable_qk_layernorm or tc.mha_qkv_weight_normalization or tc.mha_output_weight_normalization:
+        bad.append("qk-layernorm / weight-norm")
+    if tc.scale_residual is not None:
+        bad.append("scale_residual")
+    if not tc.use_swiglu and tc.ffn_inner_activation_name != "relu":
+        bad.append(f"ffn activation {tc.ffn_inner_activation_name}")
+    if bad:
+        raise NotImplementedError(f"{name}: not implemented on the HIP path: {', '.join(bad)}")
+
+
+def parameter_spec(config: TwoTowerDiffusionLCModelConfig) -> List[Tuple[str, Tuple[int, ...], str]]:
+    """(name, shape, kind) of every parameter/buffer, named like the reference's state dict."""
+    d, D = config.model_dim, config.sonar_embed_dim
+    spec: List[Tuple[str, Tuple[int, ...], str]] = [
+        ("sonar_normalizer.center", (D,), "zeros"), ("sonar_normalizer.scale", (D,), "ones"),
+        ("encoder_frontend.pre_linear.weight", (d, D), "matrix"), ("encoder_frontend.pre_linear.bias", (d,), "zeros"),
+    ]
+    if config.context_encoder.pos_embedding_style == "learned":
+        spec.append(("encoder_frontend.pos_encoder.weight", (config.max_seq_len, d), "pos"))
+
+    def stack(prefix: str, tc: TransformerConfig, denoiser: bool) -> None:
+        F = tc.allocated_ffn_dim()
+        ln_bias = tc.layer_normalization_style == "standard"
+
+        def norm(n: str) -> None:
+            spec.append((f"{n}.weight", (d,), "ones"))
+            if ln_bias:
+                spec.append((f"{n}.bias", (d,), "zeros"))
+
+        for i in range(tc.num_layers):
+            p = f"{prefix}.layers.{i}"
+            norm(f"{p}.self_attn_layer_norm")
+            if denoiser:
+                norm(f"{p}.cross_attention_layer_norm")
+            norm(f"{p}.ffn_layer_norm")
+            for attn in (["self_attn", "cross_attention"] if denoiser else ["self_attn"]):
+                for proj in ("q_proj", "k_proj", "v_proj"):
+                    spec.append((f"{p}.{attn}.{proj}.weight", (d, d), "matrix"))
+                    spec.append((f"{p}.{attn}.{proj}.bias", (d,), "zeros"))
+                spec.append((f"{p}.{attn}.output_proj.weight", (d, d), "matrix"))
+                if tc.mha_output_proj_bias:
+                    spec.append((f"{p}.{attn}.output_proj.bias", (d,), "zeros"))
+            if tc.use_swiglu:
+                spec.append((f"{p}.ffn.gate_proj.weight", (F, d), "matrix"))
+                spec.append((f"{p}.ffn.gate_proj.bias", (F,), "zeros"))
+            spec.append((f"{p}.ffn.inner_proj.weight", (F, d), "matrix"))
+            spec.append((f"{p}.ffn.inner_proj.bias", (F,), "zeros"))
+            spec.append((f"{p}.ffn.output_proj.weight", (d, F), "matrix"))
+            spec.append((f"{p}.ffn.output_proj.bias", (d,), "zeros"))
+            if denoiser:
+                spec.append((f"{p}.modulator.fc.weight", (9 * d, d), "modulator"))
+                spec.append((f"{p}.modulator.fc.bias", (9 * d,), "modulator"))
+        norm(f"{prefix}.layer_norm")
+
+    stack("context_encoder", config.context_encoder, denoiser=False)
+    spec += [
+        ("denoiser.embed_time.fc1.weight", (d, TIMESTEP_FREQ_DIM), "matrix"), ("denoiser.embed_time.fc1.bias", (d,), "zeros"),
+        ("denoiser.embed_time.fc2.weight", (d, d), "matrix"), ("denoiser.embed_time.fc2.bias", (d,), "zeros"),
+        ("denoiser.initial_proj.fc.weight", (d, D), "matrix"), ("denoiser.initial_proj.fc.bias", (d,), "zeros"),
+        ("denoiser.final_proj.fc.weight", (D, d), "matrix"), ("denoiser.final_proj.fc.bias", (D,), "zeros"),
+    ]
+    stack("denoiser", config.denoiser, denoiser=True)
+    return spec
+
+
+class DeviceSession:
+    """Caches and scratch of one batch of documents inside a torch-owned workspace."""
+
+    def __init__(self, model: "TwoTowerDiffusionLCModel", max_batch: int, max_ctx: int, max_steps: int) -> None:
+        self.model = model
+        self.dims = (max_batch, max_ctx, max_steps)
+        nbytes = C.c_size_t(0)
+        _hip.check(_hip.lib.lcmhip_session_workspace_bytes(model._handle, max_batch, max_ctx, max_steps, C.byref(nbytes)))
+        self.workspace = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=model.device)
+        base = (self.workspace.data_ptr() + 255) // 256 * 256
+        self._h = C.c_void_p()
+        _hip.check(_hip.lib.lcmhip_session_create(model._handle, max_batch, max_ctx, max_steps, C.c_void_p(base),
+                                                  nbytes.value, C.byref(self._h)))
+        self.schedule_key = None
+
+    def __del__(self) -> None:
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _hip.lib.lcmhip_session_destroy(h)
+
+    def _stream(self):
+        return _hip.stream_ptr(self.model.device)
+
+    def set_schedule(self) -> None:
+        m = self.model
+        sch = m.noise_scheduler
+        key = m._schedule_key()
+        if key == self.schedule_key:
+            return
+        ts = [int(t) for t in sch.timesteps.tolist()]
+        ts_arr = (C.c_int32 * len(ts))(*ts)
+        ac = sch.alphas_cumprod.tolist()
+        ac_arr = (C.c_float * len(ac))(*ac)
+        params = _hip.DenoiseParams(
+            guidance_scale=float(m.guidance_scale), guidance_rescale=float(m.guidance_rescale),
+            ddim_eta=float(m.ddim_eta), epsilon_scaling=float(m.epsilon_scaling) if m.epsilon_scaling else 0.0,
+            clip_noise=float(m.clip_noise), init_noise_sigma=float(sch.init_noise_sigma),
+            prediction_type=_hip.PRED[sch.prediction_type], clip_sample=int(sch.config.clip_sample),
+            clip_sample_range=float(sch.config.clip_sample_range))
+        if sch.config.thresholding:
+            raise NotImplementedError("dynamic thresholding is not implemented on the HIP path")
+        _hip.check(_hip.lib.lcmhip_session_set_schedule(
+            self._h, ts_arr, len(ts), ac_arr, len(ac), float(sch.final_alpha_cumprod), sch.step_ratio,
+            C.byref(params), self._stream()))
+        self.schedule_key = key
+
+    def reset(self, n_docs: int) -> None:
+        _hip.check(_hip.lib.lcmhip_session_reset(self._h, n_docs, self._stream()))
+
+    def append(self, x: Tensor, normalized: bool) -> None:
+        """x: (n_active, s, D) embeddings of the next s context positions."""
+        _hip.require_gpu(x, "context embeddings")
+        x32 = x.float().contiguous()
+        assert x32.dim() == 3 and x32.shape[0] == self.num_active, (tuple(x32.shape), self.num_active)
+        _hip.check(_hip.lib.lcmhip_context_append(self._h, _hip.ptr(x32), x32.shape[1], int(normalized), self._stream()))
+
+    def denoise(self, noise: Tensor, trace: Optional[Tensor] = None) -> Tensor:
+        """noise: (n_active, D) N(0, 1) draws -> next sentence embedding (n_active, D) fp32."""
+        _hip.require_gpu(noise, "noise")
+        nz = noise.float().contiguous()
+        assert nz.shape[0] == self.num_active
+        out = torch.empty_like(nz)
+        _hip.check(_hip.lib.lcmhip_denoise(self._h, _hip.ptr(nz), _hip.ptr(out), _hip.ptr(trace), self._stream()))
+        return out
+
+    def reorder(self, order) -> None:
+        idx = [int(i) for i in (order.tolist() if isinstance(order, Tensor) else order)]
+        if idx == list(range(self.num_active)):
+            return
+        arr = (C.c_int32 * len(idx))(*idx)
+        _hip.check(_hip.lib.lcmhip_session_reorder(self._h, arr, len(idx), self._stream()))
+
+    @property
+    def context_len(self) -> int:
+        return _hip.lib.lcmhip_session_context_len(self._h)
+
+    @property
+    def num_active(self) -> int:
+        return _hip.lib.lcmhip_session_num_active(self._h)
+
+    def read_context(self, row: int) -> Tensor:
+        out = torch.empty(self.context_len, self.model.model_dim, dtype=torch.float32, device=self.model.device)
+        _hip.check(_hip.lib.lcmhip_session_read_context(self._h, row, _hip.ptr(out), self._stream()))
+        return out
+
+    def profile_enable(self, on: bool) -> None:
+        _hip.check(_hip.lib.lcmhip_session_profile_enable(self._h, int(on)))
+
+    def profile(self) -> List[dict]:
+        rows = (_hip.ProfileRow * 64)()
+        n = C.c_int32(0)
+        _hip.check(_hip.lib.lcmhip_session_profile(self._h, rows, 64, C.byref(n), self._stream()))
+        return [dict(name=rows[i].name.decode(), launches=rows[i].launches, total_ms=rows[i].total_ms,
+                     bytes=rows[i].bytes, flops=rows[i].flops) for i in range(n.value)]
+
+
+class DeviceContext:
+    """Handle of the contextualizer output kept on the device (what the reference passes around as
+    the `context` EmbeddingsBatch).  `seqs` reads it back when the session keeps a copy
+    (LCMHIP_KEEP_CONTEXT=1)."""
+
+    def __init__(self, session: Optional[DeviceSession], length: int) -> None:
+        self.session = session
+        self.length = length
+        self.padding_mask = None
+
+    @property
+    def seqs(self) -> Tensor:
+        s = self.session
+        return torch.stack([s.read_context(i) for i in range(s.num_active)]).to(s.model.dtype)
+
+
+class TwoTowerDiffusionLCModel(AbstractLCModel):
+    config: TwoTowerDiffusionLCModelConfig
+
+    def __init__(self, config: TwoTowerDiffusionLCModelConfig, *, device=None, dtype: Optional[torch.dtype] = None,
+                 seed: Optional[int] = None) -> None:
+        super().__init__(config)
+        device = torch.device(device if device is not None else "cuda")
+        if device.type != "cuda":
+            raise RuntimeError("TwoTowerDiffusionLCModel runs only on a GPU (HIP path); there is no CPU fallback")
+        dtype = dtype or torch.float32
+        _hip.dtype_code(dtype)
+        _check_supported("context_encoder", config.context_encoder)
+        _check_supported("denoiser", config.denoiser)
+        if config.denoiser.timestep_embed_dim != config.model_dim:
+            raise ValueError("timestep_embed_dim must equal model_dim")
+        self.model_dim = config.model_dim
+        self.sonar_embed_dim = config.sonar_embed_dim
+        self._spec = parameter_spec(config)
+        self._params: Dict[str, Tensor] = {
+            name: torch.empty(shape, dtype=dtype, device=device) for name, shape, _ in self._spec}
+        self.init_parameters(seed if seed is not None else 0)
+        self.sonar_normalizer = SonarNormalizer(SonarNormalizerConfig(dim=config.sonar_embed_dim), device=device, dtype=dtype)
+        # the normalizer's buffers ARE the model's tensors (one storage, like a registered submodule)
+        self.sonar_normalizer.center = self._params["sonar_normalizer.center"]
+        self.sonar_normalizer.scale = self._params["sonar_normalizer.scale"]
+        self.noise_scheduler = DDIMScheduler(config.noise_scheduler)
+        self._handle = C.c_void_p()
+        self._bind()
+        self._session_pool: List[DeviceSession] = []
+
+    # ---- parameters ---------------------------------------------------------------------------------
+    def init_parameters(self, seed: int = 0, matrix_std: float = 0.02, modulator_std: float = 0.0) -> None:
+        """Seeded initialisation: N(0, matrix_std) matrices, zero biases, unit norms, N(0, 1)
+        learned positions (frontend.py:113-125) and zero adaLN modulators (lcm_denoiser.py:55-58)
+        unless `modulator_std` > 0."""
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        for name, shape, kind in self._spec:
+            t = self._params[name]
+            if kind == "zeros":
+                t.zero_()
+            elif kind == "ones":
+                t.fill_(1.0)
+            else:
+                std = {"matrix": matrix_std, "pos": self.config.frontend.embedding_std, "modulator": modulator_std}[kind]
+                if std == 0.0:
+                    t.zero_()
+                else:
+                    t.copy_(torch.randn(shape, generator=g, device=t.device, dtype=torch.float32) * std)
+
+    def state_dict(self) -> Dict[str, Tensor]:
+        return self._params
+
+    def load_state_dict(self, state_dict: Dict[str, Tensor], strict: bool = True) -> None:
+        sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+        missing = [k for k in self._params if k not in sd]
+        unexpected = [k for k in sd if k not in self._params]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict: missing keys {missing[:5]}..., unexpected keys {unexpected[:5]}...")
+        for k, dst in self._params.items():
+            if k in sd:
+                if tuple(sd[k].shape) != tuple(dst.shape):
+                    raise RuntimeError(f"load_state_dict: shape mismatch for {k}: {tuple(sd[k].shape)} vs {tuple(dst.shape)}")
+                dst.copy_(sd[k])
+
+    def num_parameters(self) -> int:
+        return sum(t.numel() for n, t in self._params.items() if not n.startswith("sonar_normalizer."))
+
+    def _bind(self) -> None:
+        c = self.config
+
+        def tower(tc: TransformerConfig) -> _hip.TowerDesc:
+            return _hip.TowerDesc(
+                num_layers=tc.num_layers, num_heads=tc.num_attn_heads, ffn_dim=tc.allocated_ffn_dim(),
+                norm_kind=_NORM_KIND[tc.layer_normalization_style],
+                ffn_kind=_hip.FFN_SWIGLU if tc.use_swiglu else _hip.FFN_RELU,
+                pos_kind=_POS_KIND[tc.pos_embedding_style], out_proj_bias=int(tc.mha_output_proj_bias),
+                rope_theta=float(tc.rope_theta))
+
+        desc = _hip.ModelDesc(sonar_dim=c.sonar_embed_dim, model_dim=c.model_dim, max_seq_len=c.max_seq_len,
+                              timestep_freq_dim=TIMESTEP_FREQ_DIM, dtype=_hip.dtype_code(self.dtype), norm_eps=1e-5,
+                              context=tower(c.context_encoder), denoiser=tower(c.denoiser))
+        _hip.check(_hip.lib.lcmhip_model_create(C.byref(desc), C.byref(self._handle)))
+        code = _hip.dtype_code(self.dtype)
+        for name, t in self._params.items():
+            shape = (C.c_int64 * t.dim())(*t.shape)
+            _hip.check(_hip.lib.lcmhip_model_bind_weight(self._handle, name.encode(), _hip.ptr(t), code, t.dim(), shape))
+        _hip.check(_hip.lib.lcmhip_model_finalize(self._handle))
+
+    def __del__(self) -> None:
+        pool = getattr(self, "_session_pool", None)
+        if pool:
+            pool.clear()
+        h, self._handle = getattr(self, "_handle", None), None
+        if h:
+            _hip.lib.lcmhip_model_destroy(h)
+
+    # ---- generation set-up ------------------------------------------------------------------------------
+    def prep_for_denoising(self, decoding_options) -> None:
+        o = decoding_options
+        self.guidance_scale = o.guidance_scale
+        self.guidance_rescale = o.guidance_rescale
+        self.initial_noise_scale = o.initial_noise_scale
+        self.timesteps = o.inference_timesteps
+        self.clip_noise = o.clip_noise
+        self.ddim_eta = o.ddim_eta
+        self.epsilon_scaling = o.epsilon_scaling
+        self.do_classifier_free_guidance = self.guidance_scale != 1.0
+        self.noise_scheduler.set_timesteps(self.timesteps, device=self.device)
+        self.noise_scheduler.init_noise_sigma = self.initial_noise_scale
+        if o.thresholding:
+            raise NotImplementedError("dynamic thresholding is not implemented on the HIP path")
+        if o.ddim_eta != 0.0:
+            raise NotImplementedError("ddim_eta != 0 (stochastic DDIM) is not implemented on the HIP path")
+
+    def _schedule_key(self):
+        s = self.noise_scheduler
+        return (tuple(s.timesteps.tolist()), self.guidance_scale, self.guidance_rescale, self.ddim_eta,
+                self.epsilon_scaling, self.clip_noise, s.init_noise_sigma, s.prediction_type)
+
+    def acquire_session(self, max_batch: int, max_ctx: int) -> DeviceSession:
+        assert hasattr(self, "clip_noise"), (
+            "The model is not properly set for decoding, make sure to call `model.prep_for_denoising()`")
+        steps = len(self.noise_scheduler.timesteps)
+        for i, s in enumerate(self._session_pool):
+            if s.dims[0] >= max_batch and s.dims[1] >= max_ctx and s.dims[2] >= steps:
+                sess = self._session_pool.pop(i)
+                break
+        else:
+            self._session_pool.clear()   # one workspace at a time: they are large
+            sess = DeviceSession(self, max_batch, max_ctx, steps)
+        sess.set_schedule()
+        return sess
+
+    def release_session(self, sess: Optional[DeviceSession]) -> None:
+        if sess is not None and not self._session_pool:
+            self._session_pool.append(sess)
+
+    def _session_for(self, bag: LCMIncrementalStateBag, batch_size: int) -> DeviceSession:
+        if bag.session is None:
+            bag.session = self.acquire_session(batch_size, bag.max_num_steps)
+            bag.session.reset(batch_size)
+        return bag.session
+
+    # ---- reference API ------------------------------------------------------------------------------------
+    def sample_initial_noise_vectors(self, batch_size: int) -> Tensor:
+        """N(0, 1) draws for the next sentence; the scheduler's sigma and the clip are applied by
+        the denoising kernel (reference: builder.py:244-260 returns them already scaled)."""
+        assert hasattr(self, "clip_noise"), (
+            "The model is not properly set for decoding, make sure to call `model.prep_for_denoising()`")
+        return torch.randn(batch_size, 1, self.config.sonar_embed_dim, device=self.device)
+
+    @torch.inference_mode()
+    def encode(self, batch: EmbeddingsBatch, state_bag: Optional[LCMIncrementalStateBag] = None,
+               *, normalized: bool = True, **kwargs) -> DeviceContext:
+        """Contextualizes `batch.seqs` (normalized SONAR embeddings) after what the bag already holds."""
+        if state_bag is None:
+            raise NotImplementedError("encode() without a state bag (no KV cache) is not implemented on the HIP path")
+        if batch.padding_mask is not None:
+            raise ValueError("the contextualizer takes unpadded positions (the generator never pads them)")
+        sess = self._session_for(state_bag, batch.seqs.shape[0])
+        sess.append(batch.seqs, normalized=normalized)
+        return DeviceContext(sess, sess.context_len)
+
+    @torch.inference_mode()
+    def predict_next_sentence(self, batch: EmbeddingsBatch, context: DeviceContext, temperature: float = 1.0,
+                              state_bag: Optional[LCMIncrementalStateBag] = None,
+                              context_state_bag: Optional[LCMIncrementalStateBag] = None,
+                              noise: Optional[Tensor] = None, trace: Optional[Tensor] = None,
+                              **kwargs) -> Tuple[EmbeddingsBatch, DeviceContext]:
+        """batch.seqs (B, 1, D): the latest raw SONAR embedding of every active document.
+        Returns the next embedding (B, 1, D) fp32 and the grown context handle.  `noise` (B, 1, D) or
+        (B, D) replaces the internal N(0, 1) draw."""
+        assert context_state_bag is not None, "Expected a state_bag to incrementally encode the context"
+        x = batch.seqs
+        sess = self._session_for(context_state_bag, x.shape[0])
+        sess.append(x, normalized=False)           # normalizer fused into the staging kernel
+        context_state_bag.increment_step_nr(x.shape[1])
+        if noise is None:
+            noise = self.sample_initial_noise_vectors(x.shape[0])
+        out = sess.denoise(noise.reshape(x.shape[0], -1), trace)
+        return EmbeddingsBatch(out.unsqueeze(1), None), DeviceContext(sess, sess.context_len)
+
+    # classifier-free guidance is selected by `prep_for_denoising`; both entry points share the kernel loop
+    predict_next_sentence_with_cf_guidance = predict_next_sentence
+
+
+def create_two_tower_diffusion_lcm_model(config: TwoTowerDiffusionLCModelConfig, *, device=None,
+                                         dtype: Optional[torch.dtype] = None,
+                                         seed: Optional[int] = None) -> TwoTowerDiffusionLCModel:
+    return TwoTowerDiffusionLCModel(config, device=device, dtype=dtype, seed=seed)

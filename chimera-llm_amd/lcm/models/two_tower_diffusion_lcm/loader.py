@@ -1,0 +1,51 @@
+"""Builds a model from a card (reference: lcm/models/two_tower_diffusion_lcm/loader.py:19-44 and
+lcm/models/base_lcm/loader.py:24-30 for the `module.` prefix of DDP checkpoints)."""
+
+import dataclasses
+from typing import Any, Dict
+
+import torch
+
+from lcm.models.two_tower_diffusion_lcm.builder import (
+    TwoTowerDiffusionLCModel,
+    TwoTowerDiffusionLCModelConfig,
+    lcm_archs,
+)
+
+
+def _apply_overrides(obj: Any, overrides: Dict[str, Any]) -> Any:
+    """`model_config` of a card: nested dicts override dataclass fields."""
+    for key, value in overrides.items():
+        if not hasattr(obj, key):
+            raise ValueError(f"model_config: unknown field '{key}' for {type(obj).__name__}")
+        cur = getattr(obj, key)
+        if dataclasses.is_dataclass(cur) and isinstance(value, dict):
+            _apply_overrides(cur, value)
+        else:
+            setattr(obj, key, value)
+    return obj
+
+
+def load_two_tower_diffusion_lcm_model(name_or_card, device=None, dtype=None) -> TwoTowerDiffusionLCModel:
+    from lcm.models.sonar_normalizer.loader import load_sonar_normalizer_model
+    from lcm.utils.card_utils import resolve_card, resolve_checkpoint_path
+
+    card = resolve_card(name_or_card)
+    arch = card.get("model_arch", "toy_two_tower_diffusion_lcm")
+    config: TwoTowerDiffusionLCModelConfig = lcm_archs.get_config(arch)
+    if card.get("model_config"):
+        _apply_overrides(config, card["model_config"])
+    model = TwoTowerDiffusionLCModel(config, device=device, dtype=dtype, seed=card.get("seed"))
+    ckpt = resolve_checkpoint_path(card)
+    if ckpt is not None:
+        blob = torch.load(ckpt, map_location="cpu", weights_only=True)
+        sd = blob["model"] if "model" in blob else blob
+        # checkpoints written before the normalizer was part of the model do not carry its buffers
+        strict = any(k.endswith("sonar_normalizer.center") for k in sd)
+        model.load_state_dict(sd, strict=strict)
+        if strict:
+            return model
+    if config.sonar_normalizer_name is not None:
+        normalizer = load_sonar_normalizer_model(config.sonar_normalizer_name, device=model.device, dtype=model.dtype)
+        model.sonar_normalizer.load_state_dict(normalizer.state_dict())
+    return model

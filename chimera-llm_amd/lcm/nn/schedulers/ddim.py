@@ -1,0 +1,160 @@
+"""Host half of the DDIM scheduler: noise tables and the inference timestep list.
+
+The tensor half (get_epsilon / classifier-free guidance / step) runs in the fused HIP kernel
+`lcmhip_ddim_cfg_step`; `step()` / `get_epsilon()` below call it for GPU tensors so that the
+reference's per-call API (lcm/nn/schedulers/ddim.py:358-510, 561-587) keeps working.
+Tables follow ddim.py:135-207 (cosine / linear betas, zero-terminal-SNR rescale, cumprod) and
+the timestep list ddim.py:282-356, evaluated with the same fp32 torch expressions so that the
+values are bit-identical (the truncating integer `arange` of the "trailing" spacing included).
+"""
+
+import math
+from dataclasses import dataclass
+from typing import Literal, NamedTuple, Optional
+
+import torch
+from torch import Tensor
+
+from lcm import _hip
+
+
+class DDIMSchedulerOutput(NamedTuple):
+    prev_sample: Tensor
+    pred_original_sample: Tensor
+
+
+@dataclass
+class DDIMSchedulerConfig:
+    num_diffusion_train_steps: int = 1000
+    beta_start: float = 0.0001
+    beta_end: float = 0.02
+    beta_schedule: Literal["linear", "scaled_linear", "squaredcos_cap_v2", "sigmoid"] = "squaredcos_cap_v2"
+    scaled_linear_exponent: float = 2.0
+    sigmoid_schedule_alpha: float = 1.5
+    sigmoid_schedule_beta: float = 0
+    clip_sample: bool = False
+    clip_sample_range: float = 1.0
+    set_alpha_to_one: bool = True
+    prediction_type: Literal["sample", "epsilon", "v_prediction"] = "sample"
+    thresholding: bool = False
+    dynamic_thresholding_ratio: float = 0.995
+    sample_max_value: float = 1.0
+    rescale_betas_zero_snr: bool = True
+    timestep_spacing: Literal["linspace", "leading", "trailing"] = "trailing"
+
+
+def _cosine_betas(n: int, max_beta: float = 0.999) -> Tensor:
+    bar = [math.cos((i / n + 0.008) / 1.008 * math.pi / 2) ** 2 for i in range(n + 1)]
+    return torch.tensor([min(1 - bar[i + 1] / bar[i], max_beta) for i in range(n)], dtype=torch.float32)
+
+
+def _sigmoid_betas(n: int, alpha: float, beta: float, max_beta: float = 0.999) -> Tensor:
+    def bar(t: float) -> float:
+        t = min(max(t, 1e-32), 1 - 1e-32)
+        t = float(torch.tensor(t))  # fp32 clamp like the reference's torch.clamp(torch.tensor(t))
+        return 1 / (1 + math.exp(-(beta - alpha * math.log(t / (1 - t)))))
+
+    return torch.tensor([min(1 - bar((i + 1) / n) / bar(i / n), max_beta) for i in range(n)], dtype=torch.float32)
+
+
+def _zero_terminal_snr(betas: Tensor) -> Tensor:
+    root = torch.cumprod(1.0 - betas, dim=0).sqrt()
+    first, last = root[0].clone(), root[-1].clone()
+    root -= last
+    root *= first / (first - last)
+    bar = root**2
+    return 1 - torch.cat([bar[0:1], bar[1:] / bar[:-1]])
+
+
+class DDIMScheduler:
+    def __init__(self, config: DDIMSchedulerConfig):
+        self.config = config
+        self.num_diffusion_train_steps = n = config.num_diffusion_train_steps
+        self.prediction_type = config.prediction_type
+        kind = config.beta_schedule
+        if kind == "linear":
+            betas = torch.linspace(config.beta_start, config.beta_end, n, dtype=torch.float32)
+        elif kind == "scaled_linear":
+            e = config.scaled_linear_exponent
+            betas = torch.linspace(config.beta_start ** (1 / e), config.beta_end ** (1 / e), n, dtype=torch.float32) ** e
+        elif kind == "squaredcos_cap_v2":
+            betas = _cosine_betas(n)
+        elif kind == "sigmoid":
+            betas = _sigmoid_betas(n, config.sigmoid_schedule_alpha, config.sigmoid_schedule_beta)
+        else:
+            raise NotImplementedError(f"We do not recognize beta_schedule={kind}")
+        if config.rescale_betas_zero_snr:
+            betas = _zero_terminal_snr(betas)
+        self.betas = betas
+        self.alphas = 1.0 - betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        self.final_alpha_cumprod = torch.tensor(1.0) if config.set_alpha_to_one else self.alphas_cumprod[0]
+        self.init_noise_sigma = 1.0
+        self.num_inference_steps: Optional[int] = None
+        self.timesteps: Optional[Tensor] = None
+
+    def set_timesteps(self, num_inference_steps: int, device=None) -> None:
+        n = self.num_diffusion_train_steps
+        if num_inference_steps > n:
+            raise ValueError(
+                f"`num_inference_steps`: {num_inference_steps} cannot be larger than "
+                f"`self.config.num_diffusion_train_steps`: {n}")
+        self.num_inference_steps = num_inference_steps
+        spacing = self.config.timestep_spacing
+        if spacing == "trailing":
+            ts = torch.arange(n, 0, -(n / num_inference_steps), dtype=torch.long).round() - 1
+        elif spacing == "leading":
+            ts = torch.arange(0, n, n // num_inference_steps, dtype=torch.long).flip(0).round()
+        elif spacing == "linspace":
+            ts = torch.linspace(0, n - 1, num_inference_steps, dtype=torch.long).flip(0).round()
+        else:
+            raise ValueError(f"{spacing} is not supported. Please make sure to choose one of 'leading' or 'trailing'.")
+        self.timesteps = ts  # host tensor: the schedule is compiled into the session, never read on device
+
+    # ---- scalar helpers -------------------------------------------------------------------------
+    @property
+    def step_ratio(self) -> int:
+        return self.num_diffusion_train_steps // self.num_inference_steps
+
+    def alpha_pair(self, timestep: int):
+        prev = int(timestep) - self.step_ratio
+        a_t = float(self.alphas_cumprod[int(timestep)])
+        a_prev = float(self.alphas_cumprod[prev]) if prev >= 0 else float(self.final_alpha_cumprod)
+        return a_t, a_prev
+
+    def _params(self, eta, epsilon_scaling, prediction_type, clip_noise=float("inf")) -> "_hip.DenoiseParams":
+        if self.config.thresholding:
+            raise NotImplementedError("dynamic thresholding is not implemented on the HIP path")
+        return _hip.DenoiseParams(
+            guidance_scale=1.0, guidance_rescale=0.0, ddim_eta=float(eta),
+            epsilon_scaling=float(epsilon_scaling) if epsilon_scaling else 0.0,
+            clip_noise=float(min(clip_noise, 3.0e38)), init_noise_sigma=float(self.init_noise_sigma),
+            prediction_type=_hip.PRED[prediction_type or self.prediction_type],
+            clip_sample=int(self.config.clip_sample), clip_sample_range=float(self.config.clip_sample_range))
+
+    # ---- per-call tensor API (GPU tensors, fp32) ---------------------------------------------------
+    def step(self, model_output: Tensor, timestep, sample: Tensor, eta: float = 0.0,
+             prediction_type: Optional[str] = None, epsilon_scaling: Optional[float] = None) -> DDIMSchedulerOutput:
+        if self.num_inference_steps is None:
+            raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
+        _hip.require_gpu(sample, "sample")
+        x = sample.float().contiguous()
+        out = model_output.float().contiguous()
+        dim = x.shape[-1]
+        rows = x.numel() // dim
+        prev, x0 = torch.empty_like(x), torch.empty_like(x)
+        a_t, a_prev = self.alpha_pair(int(timestep))
+        p = self._params(eta, epsilon_scaling, prediction_type)
+        _hip.check(_hip.lib.lcmhip_ddim_cfg_step(_hip.ptr(x), _hip.ptr(out), None, _hip.ptr(prev), _hip.ptr(x0),
+                                                 rows, dim, a_t, a_prev, p, _hip.stream_ptr(x.device)))
+        return DDIMSchedulerOutput(prev, x0)
+
+    def get_epsilon(self, model_output: Tensor, sample: Tensor, timestep) -> Tensor:
+        a_t = self.alphas_cumprod[int(timestep)].item()
+        if self.prediction_type == "epsilon":
+            return model_output
+        if self.prediction_type == "sample":
+            return (sample - a_t**0.5 * model_output) / (1 - a_t) ** 0.5
+        if self.prediction_type == "v_prediction":
+            return a_t**0.5 * model_output + (1 - a_t) ** 0.5 * sample
+        raise ValueError(f"unknown prediction type {self.prediction_type}")

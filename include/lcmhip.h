@@ -1,0 +1,242 @@
+/*
+ * lcmhip.h -- C ABI of liblcm_hip.so: the MI355X (gfx950) generation path of the two-tower
+ * diffusion Large Concept Model.
+ *
+ * The reference (viasky657/Chimera-LLM) has no FFI for this path: its boundary is the Python
+ * API of lcm/inference/two_tower_diffusion_lcm/generator.py and
+ * lcm/models/two_tower_diffusion_lcm/builder.py.  Each entry point below names the reference
+ * function whose arithmetic it replaces (file:line relative to the reference root).
+ *
+ * Conventions
+ *  - every function returns 0 on success and a negative LCMHIP_ERR_* code otherwise;
+ *    lcmhip_last_error() returns a thread-local message for the last failure on this thread;
+ *    nothing throws across the boundary.
+ *  - all tensor pointers are BORROWED device pointers (row-major, contiguous unless a stride
+ *    is given); weights must outlive the model handle; workspaces are allocated by the caller.
+ *  - `stream` is a hipStream_t passed as void*; every kernel is enqueued on it; no call
+ *    synchronises the device unless its comment says so.
+ *  - a session is not thread-safe; use one session per (process, device).
+ */
+#ifndef LCMHIP_H
+#define LCMHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LCMHIP_OK 0
+#define LCMHIP_ERR_INVALID (-1)     /* bad argument / shape the kernels do not support */
+#define LCMHIP_ERR_HIP (-2)         /* a HIP runtime call failed */
+#define LCMHIP_ERR_UNSUPPORTED (-3) /* valid in the reference, not implemented here */
+#define LCMHIP_ERR_STATE (-4)       /* call sequence error (e.g. denoise before set_schedule) */
+
+enum { LCMHIP_F32 = 0, LCMHIP_BF16 = 1 };
+enum { LCMHIP_NORM_LAYERNORM = 0, LCMHIP_NORM_RMS = 1 };
+enum { LCMHIP_FFN_RELU = 0, LCMHIP_FFN_SWIGLU = 1 };
+enum { LCMHIP_POS_NONE = 0, LCMHIP_POS_LEARNED = 1, LCMHIP_POS_ROPE = 2 };
+enum { LCMHIP_PRED_SAMPLE = 0, LCMHIP_PRED_EPSILON = 1, LCMHIP_PRED_V = 2 };
+
+/* GEMM epilogues of lcmhip_gemm (C = A * W^T, W stored (N, K) like torch.nn.Linear.weight) */
+enum {
+    LCMHIP_EPI_STORE = 0,     /* out[m][n] = acc + bias[n]            (out in the operand dtype) */
+    LCMHIP_EPI_STORE_F32 = 1, /* same, fp32 output                                               */
+    LCMHIP_EPI_RELU = 2,      /* out = max(acc + bias, 0)                                        */
+    LCMHIP_EPI_SWIGLU = 3,    /* out = (acc2 + bias2) * silu(acc + bias); W = gate, W2 = inner   */
+    LCMHIP_EPI_RESID = 4      /* resid[m][n] += gate[n] * (acc + bias[n]); fp32, gate optional   */
+};
+
+typedef struct lcmhip_model lcmhip_model;
+typedef struct lcmhip_session lcmhip_session;
+
+/* One transformer stack (contextualizer or denoiser); lcm/nn/transformer/factory.py:47-123. */
+typedef struct {
+    int32_t num_layers;
+    int32_t num_heads;     /* model_dim / num_heads must be 128 */
+    int32_t ffn_dim;       /* inner width actually allocated (after GLU rounding) */
+    int32_t norm_kind;     /* LCMHIP_NORM_* */
+    int32_t ffn_kind;      /* LCMHIP_FFN_*  */
+    int32_t pos_kind;      /* LCMHIP_POS_*  */
+    int32_t out_proj_bias; /* 0 / 1 */
+    float rope_theta;
+} lcmhip_tower_desc;
+
+/* lcm/models/two_tower_diffusion_lcm/builder.py:49-81 (TwoTowerDiffusionLCModelConfig). */
+typedef struct {
+    int32_t sonar_dim;         /* 1024 */
+    int32_t model_dim;
+    int32_t max_seq_len;
+    int32_t timestep_freq_dim; /* 256, lcm/nn/timestep_encoder.py:28 */
+    int32_t dtype;             /* LCMHIP_F32 or LCMHIP_BF16: dtype of every bound weight and of GEMM operands */
+    float norm_eps;
+    lcmhip_tower_desc context;
+    lcmhip_tower_desc denoiser;
+} lcmhip_model_desc;
+
+/* Options of DiffusionLCMGeneratorOptions that reach the arithmetic
+ * (lcm/inference/two_tower_diffusion_lcm/generator.py:29-73) plus the scheduler config bits of
+ * lcm/nn/schedulers/ddim.py:48-132 that `step` reads. */
+typedef struct {
+    float guidance_scale;
+    float guidance_rescale;
+    float ddim_eta;            /* only 0 is implemented */
+    float epsilon_scaling;     /* <= 0: disabled */
+    float clip_noise;
+    float init_noise_sigma;
+    int32_t prediction_type;   /* LCMHIP_PRED_* configured for the model */
+    int32_t clip_sample;       /* 0 / 1 */
+    float clip_sample_range;
+} lcmhip_denoise_params;
+
+/* One row of lcmhip_session_profile(): time spent in one kernel family while profiling was on. */
+typedef struct {
+    char name[48];
+    int64_t launches;
+    double total_ms;
+    double bytes;  /* algorithmic bytes moved, summed over launches */
+    double flops;  /* algorithmic flops, summed over launches */
+} lcmhip_profile_row;
+
+const char* lcmhip_last_error(void);
+int lcmhip_version(void);
+
+/* ---- model ------------------------------------------------------------------------------ */
+
+/* Replaces TwoTowerDiffusionLCModelBuilder.build_model (builder.py:532-557): creates an empty
+ * weight table for `desc`. */
+int lcmhip_model_create(const lcmhip_model_desc* desc, lcmhip_model** out);
+
+/* Binds one state-dict tensor by its reference name (e.g.
+ * "denoiser.layers.3.cross_attention.q_proj.weight"; names as produced by the modules of
+ * builder.py:104-121).  `dtype` must equal desc.dtype.  Replaces load_state_dict of
+ * lcm/models/base_lcm/loader.py:24-30 + fairseq2 StandardModelLoader. */
+int lcmhip_model_bind_weight(lcmhip_model* m, const char* name, const void* ptr, int32_t dtype,
+                             int32_t ndim, const int64_t* shape);
+
+/* Checks that every tensor the configured architecture needs is bound with the right shape. */
+int lcmhip_model_finalize(lcmhip_model* m);
+int lcmhip_model_destroy(lcmhip_model* m);
+
+/* ---- session: caches + scratch for one batch of documents --------------------------------- */
+
+int lcmhip_session_workspace_bytes(const lcmhip_model* m, int32_t max_batch, int32_t max_ctx,
+                                   int32_t max_steps, size_t* bytes);
+
+/* `workspace` (device, 256-byte aligned, `bytes` long) holds the contextualizer KV cache
+ * (lcm/nn/incremental_state.py:14-43), the per-layer cross-attention K/V of the context, the
+ * adaLN modulation table and all activations.  Replaces the LCMIncrementalStateBag pair of
+ * generator.py:172-181. */
+int lcmhip_session_create(lcmhip_model* m, int32_t max_batch, int32_t max_ctx, int32_t max_steps,
+                          void* workspace, size_t bytes, lcmhip_session** out);
+int lcmhip_session_destroy(lcmhip_session* s);
+
+/* Replaces TwoTowerDiffusionLCModel.prep_for_denoising (builder.py:215-242) together with the
+ * timestep-only parts of the denoiser: DiTTimestepEncoder.forward (lcm/nn/timestep_encoder.py:
+ * 106-122) and AdaLNModulator.forward (lcm/nn/denoisers/lcm_denoiser.py:60-64) are evaluated
+ * once per timestep into a table, and the unconditional rows' cross-attention output
+ * (lcm_denoiser.py:505-513 with a zero-length context) into one vector per layer.
+ * `timesteps` / `alphas_cumprod` are HOST arrays: the list of DDIMScheduler.set_timesteps
+ * (ddim.py:333-347) and the table of ddim.py:190-191; `step_ratio` = T // S (ddim.py:421-423).
+ * Synchronises `stream` before returning. */
+int lcmhip_session_set_schedule(lcmhip_session* s, const int32_t* timesteps, int32_t n_steps,
+                                const float* alphas_cumprod, int32_t num_train_steps,
+                                float final_alpha_cumprod, int32_t step_ratio,
+                                const lcmhip_denoise_params* params, void* stream);
+
+/* Starts a new batch of `n_docs` documents: empty context, identity row->cache-slot map. */
+int lcmhip_session_reset(lcmhip_session* s, int32_t n_docs, void* stream);
+
+/* Replaces SonarNormalizer.normalize + TwoTowerDiffusionLCModel.encode with a state bag
+ * (builder.py:161-191, 356-364; frontend.py:127-152; decoder.py:131-176; attention.py:201-298)
+ * and the k_proj/v_proj of every denoiser cross-attention layer for the new positions
+ * (lcm_denoiser.py:505-513).  `x` is (n_active, s, sonar_dim) fp32 SONAR embeddings for the next
+ * `s` positions of every active document: raw when `normalized` == 0 (the normalizer is applied
+ * while staging), already normalized otherwise (what TwoTowerDiffusionLCModel.encode receives). */
+int lcmhip_context_append(lcmhip_session* s, const float* x, int32_t n_tokens, int32_t normalized,
+                          void* stream);
+
+/* Replaces the sampling loop of predict_next_sentence[_with_cf_guidance] (builder.py:299-338,
+ * 366-461): sample_initial_noise_vectors with host-supplied N(0,1) `noise` (n_active, sonar_dim)
+ * fp32, LCMDenoiser.forward per timestep, DDIMScheduler.get_epsilon / step,
+ * apply_classifier_free_guidance, latent clipping and SonarNormalizer.denormalize.
+ * `out` (n_active, sonar_dim) fp32 receives the next sentence embedding.  If `latents_trace`
+ * is not NULL it receives prev_sample after every step, (n_steps, n_active, sonar_dim) fp32. */
+int lcmhip_denoise(lcmhip_session* s, const float* noise, float* out, float* latents_trace,
+                   void* stream);
+
+/* Replaces TwoTowerDiffusionLCMGenerator.reorder_state (generator.py:442-466) for the caches:
+ * afterwards active row i is the row that was `order[i]` (HOST array, strictly increasing). No
+ * cache bytes move. */
+int lcmhip_session_reorder(lcmhip_session* s, const int32_t* order, int32_t n, void* stream);
+
+int lcmhip_session_context_len(const lcmhip_session* s);
+int lcmhip_session_num_active(const lcmhip_session* s);
+
+/* Copies the contextualizer output of active row `row`, positions [0, context_len), as fp32
+ * (context_len, model_dim) into `out` (device).  Only kept when the session was created with
+ * LCMHIP_KEEP_CONTEXT=1 in the environment (tests); otherwise returns LCMHIP_ERR_STATE. */
+int lcmhip_session_read_context(lcmhip_session* s, int32_t row, float* out, void* stream);
+
+/* Per-kernel timing with HIP events on `stream`, for roofline accounting.  While enabled, every
+ * launch is bracketed by an event pair (slower end-to-end; never enable inside a timed region
+ * whose wall time is reported).  lcmhip_session_profile synchronises the stream, fills at most
+ * `max_rows` rows and returns the row count through `n_rows`; it also resets the counters. */
+int lcmhip_session_profile_enable(lcmhip_session* s, int32_t on);
+int lcmhip_session_profile(lcmhip_session* s, lcmhip_profile_row* rows, int32_t max_rows,
+                           int32_t* n_rows, void* stream);
+
+/* ---- single kernels (unit parity tests and roofline microbenchmarks) ----------------------- */
+
+/* SonarNormalizer.normalize / denormalize, lcm/models/sonar_normalizer/builder.py:121-137.
+ * x, y: (rows, dim) in `dtype`; center/scale: (dim,) in `dtype`; clip_min/clip_max optional
+ * (dim,) or NULL (builder.py:126-127, 131-132). */
+int lcmhip_normalize(const void* x, const void* center, const void* scale, const void* clip_min,
+                     const void* clip_max, void* y, int64_t rows, int32_t dim, int32_t dtype,
+                     void* stream);
+int lcmhip_denormalize(const void* x, const void* center, const void* scale, const void* clip_min,
+                       const void* clip_max, void* y, int64_t rows, int32_t dim, int32_t dtype,
+                       void* stream);
+
+/* Layer/RMS norm (lcm/nn/normalization.py:73-88) fused with the adaLN modulation
+ * `h * (1 + scale) + shift` of lcm_denoiser.py:449-452.  x: (rows, dim) fp32; weight/bias:
+ * (dim,) in `dtype` (bias NULL for RMS); shift/scale: (dim,) fp32 or NULL; y: (rows, dim) in
+ * `dtype`. */
+int lcmhip_norm_modulate(const float* x, const void* weight, const void* bias, const float* shift,
+                         const float* scale, void* y, int32_t rows, int32_t dim, int32_t norm_kind,
+                         float eps, int32_t dtype, void* stream);
+
+/* C = A * W^T with a fused epilogue (LCMHIP_EPI_*); the Linear layers of fairseq2 used at
+ * attention.py:151-185, factory.py:247-254, 277-300, projection.py:80-86, frontend.py:139.
+ * A: (M, K) lda; W, W2: (N, K); bias, bias2: (N,) in `dtype` or NULL; gate: (N,) fp32 or NULL;
+ * out: (M, N) ldo -- operand dtype for STORE/RELU/SWIGLU, fp32 for STORE_F32/RESID.
+ * K must be a multiple of 128 bytes of operands, N a multiple of 32. */
+int lcmhip_gemm(const void* A, int32_t lda, const void* W, const void* W2, const void* bias,
+                const void* bias2, const float* gate, void* out, int32_t ldo, int32_t M, int32_t N,
+                int32_t K, int32_t epilogue, int32_t dtype, void* stream);
+
+/* One DDIM update for a batch of rows with optional classifier-free guidance:
+ * DDIMScheduler.get_epsilon (ddim.py:561-587), apply_classifier_free_guidance
+ * (builder.py:463-488), DDIMScheduler.step (ddim.py:358-510, eta = 0) and the latent clip of
+ * builder.py:452-454.  sample: (rows, dim) fp32 x_t; out_cond / out_uncond: (rows, dim) fp32
+ * model outputs (out_uncond NULL: no guidance, `step` is applied to out_cond with the model's
+ * prediction type); prev_sample, pred_x0: (rows, dim) fp32. */
+int lcmhip_ddim_cfg_step(const float* sample, const float* out_cond, const float* out_uncond,
+                         float* prev_sample, float* pred_x0, int32_t rows, int32_t dim,
+                         float alpha_prod_t, float alpha_prod_t_prev,
+                         const lcmhip_denoise_params* params, void* stream);
+
+/* Single-query-block attention over a per-document key/value cache: fairseq2 TorchSDPA as
+ * called at attention.py:272-279 (scale 1/sqrt(128), -inf on masked keys).
+ * q: (n_docs * s, H * 128) in `dtype`; k_cache / v_cache: (n_slots, cap, H * 128);
+ * slot_map: (n_docs,) int32 or NULL (identity); query j of a document sees keys
+ * [0, base_keys + (causal ? j + 1 : 0)).  out: like q. */
+int lcmhip_attention(const void* q, const void* k_cache, const void* v_cache, const int32_t* slot_map,
+                     void* out, int32_t n_docs, int32_t s, int32_t n_heads, int32_t cap,
+                     int32_t base_keys, int32_t causal, int32_t dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LCMHIP_H */

@@ -1,0 +1,305 @@
+"""Two-tower diffusion LCM restated in plain PyTorch-CPU (test infrastructure).
+
+Follows lcm/models/two_tower_diffusion_lcm/builder.py:161-488 (encode / denoise /
+prep_for_denoising / predict_next_sentence[_with_cf_guidance] / apply_classifier_free_guidance),
+lcm/models/two_tower_diffusion_lcm/frontend.py:127-152, lcm/nn/transformer/decoder.py:29-176,
+lcm/nn/transformer/attention.py:143-298, lcm/nn/denoisers/lcm_denoiser.py:33-64, 152-251,
+388-546, lcm/nn/timestep_encoder.py:72-122, lcm/nn/normalization.py:16-88,
+lcm/models/sonar_normalizer/builder.py:121-137, plus the fairseq2 0.3 semantics those files
+rely on (RotaryEncoder, LearnedPositionEncoder, RMSNorm, GLU/Standard FFN, TorchSDPA,
+CausalAttentionMaskFactory, FullAttentionState), which are restated from their published
+behaviour because fairseq2 is not installable here.
+"""
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+from .archs import ArchConfig, TowerConfig
+from .scheduler import DDIMSchedule
+
+
+# ----------------------------------------------------------------------------- primitives
+
+def linear(x: Tensor, sd: Dict[str, Tensor], prefix: str) -> Tensor:
+    return F.linear(x, sd[prefix + ".weight"], sd.get(prefix + ".bias"))
+
+
+def norm(x: Tensor, sd: Dict[str, Tensor], prefix: str, kind: str, eps: float) -> Tensor:
+    """lcm/nn/normalization.py:73-88.  rms = fairseq2 RMSNorm(bias=False): normalise in fp32,
+    cast back, then multiply by weight; standard = F.layer_norm with weight and bias."""
+    w = sd[prefix + ".weight"]
+    if kind == "rms":
+        xf = x.float()
+        y = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
+        return y.type_as(x) * w
+    if kind == "standard":
+        return F.layer_norm(x, (x.shape[-1],), w, sd[prefix + ".bias"], eps)
+    raise ValueError(kind)
+
+
+def rope(x: Tensor, start: int, theta: float) -> Tensor:
+    """fairseq2 RotaryEncoder: consecutive pairs (x[2i], x[2i+1]) rotated by pos * theta^(-2i/hd),
+    computed in fp32 through complex multiplication.  x: (N, H, S, hd)."""
+    hd = x.shape[-1]
+    S = x.shape[-2]
+    idx = torch.arange(0, hd, 2, dtype=torch.float32)
+    freqs = 1.0 / (theta ** (idx / hd))
+    pos = torch.arange(start, start + S, dtype=torch.float32)
+    ang = torch.outer(pos, freqs)
+    rot = torch.polar(torch.ones_like(ang), ang)                       # (S, hd/2) complex
+    xc = torch.view_as_complex(x.float().unflatten(-1, (-1, 2)).contiguous())
+    return torch.view_as_real(xc * rot).flatten(-2).type_as(x)
+
+
+def rope_explicit(x: Tensor, start: int, theta: float) -> Tensor:
+    """Second, independent statement of the same rotation (cos/sin on interleaved pairs), used by
+    the tests to cross-check `rope`."""
+    hd = x.shape[-1]
+    S = x.shape[-2]
+    out = torch.empty_like(x, dtype=torch.float32)
+    xf = x.float()
+    for s in range(S):
+        for i in range(hd // 2):
+            a = (start + s) * theta ** (-2.0 * i / hd)
+            c, sn = math.cos(a), math.sin(a)
+            x0, x1 = xf[..., s, 2 * i], xf[..., s, 2 * i + 1]
+            out[..., s, 2 * i] = x0 * c - x1 * sn
+            out[..., s, 2 * i + 1] = x0 * sn + x1 * c
+    return out.type_as(x)
+
+
+def sdpa(q: Tensor, k: Tensor, v: Tensor, key_lens: Optional[Tensor], mask: Optional[Tensor]) -> Tensor:
+    """fairseq2 TorchSDPA semantics with explicit softmax: scale 1/sqrt(hd); padded keys and
+    masked positions get -inf.  q (N,H,S,hd), k/v (N,H,Sk,hd); key_lens (N,) number of visible
+    keys per row (None = all); mask (S,Sk) additive float or None."""
+    hd = q.shape[-1]
+    w = torch.matmul(q.float(), k.float().transpose(-1, -2)) * (hd**-0.5)
+    if mask is not None:
+        w = w + mask
+    if key_lens is not None:
+        Sk = k.shape[-2]
+        pad = torch.arange(Sk)[None, :] >= key_lens[:, None]                # True = padded
+        w = w.masked_fill(pad[:, None, None, :], float("-inf"))
+    p = torch.softmax(w, dim=-1)
+    return torch.matmul(p, v.float()).type_as(q)
+
+
+def causal_mask(attn_len: int, key_len: int) -> Optional[Tensor]:
+    """fairseq2 CausalAttentionMaskFactory in eval: None when a single position is fed
+    (incremental decode attends to every cached key); otherwise the last `attn_len` rows of a
+    key_len x key_len lower-triangular mask."""
+    if attn_len <= 1:
+        return None
+    full = torch.full((key_len, key_len), float("-inf")).triu(1)
+    return full[key_len - attn_len:, :]
+
+
+class KVCache:
+    """fairseq2 IncrementalStateBag + FullAttentionState for the contextualizer
+    (lcm/nn/incremental_state.py:14-43; lcm/nn/transformer/attention.py:227-253)."""
+
+    def __init__(self, max_num_steps: int):
+        self.max_num_steps = max_num_steps
+        self.step_nr = 0
+        self.k: Dict[int, Tensor] = {}
+        self.v: Dict[int, Tensor] = {}
+
+    def increment_step_nr(self, n: int = 1) -> None:
+        if self.step_nr + n > self.max_num_steps:
+            raise ValueError(f"step_nr {self.step_nr}+{n} exceeds max_num_steps {self.max_num_steps}")
+        self.step_nr += n
+
+    def append(self, layer: int, k: Tensor, v: Tensor) -> Tuple[Tensor, Tensor]:
+        if layer in self.k:
+            self.k[layer] = torch.cat([self.k[layer], k], dim=2)
+            self.v[layer] = torch.cat([self.v[layer], v], dim=2)
+        else:
+            self.k[layer], self.v[layer] = k, v
+        return self.k[layer], self.v[layer]
+
+    def reorder(self, new_order: Tensor) -> None:
+        for d in (self.k, self.v):
+            for key in d:
+                d[key] = d[key].index_select(0, new_order)
+
+
+# ----------------------------------------------------------------------------- model
+
+class OracleTwoTower:
+    def __init__(self, cfg: ArchConfig, sd: Dict[str, Tensor]):
+        self.cfg = cfg
+        self.sd = sd
+        self.model_dim = cfg.model_dim
+        self.scheduler = DDIMSchedule(cfg.scheduler)
+
+    # -- SONAR normalizer (lcm/models/sonar_normalizer/builder.py:121-137; base arch: no clip, no fft)
+    def normalize(self, x: Tensor) -> Tensor:
+        return (x - self.sd["sonar_normalizer.center"]) / self.sd["sonar_normalizer.scale"]
+
+    def denormalize(self, x: Tensor) -> Tensor:
+        return x * self.sd["sonar_normalizer.scale"] + self.sd["sonar_normalizer.center"]
+
+    # -- attention / ffn blocks
+    def _mha(self, prefix: str, tc: TowerConfig, x_q: Tensor, x_kv: Tensor, *, key_lens=None, mask=None,
+             cache: Optional[KVCache] = None, layer: int = -1, use_rope: bool = False) -> Tensor:
+        """lcm/nn/transformer/attention.py:201-298."""
+        sd, H = self.sd, tc.num_heads
+        q = linear(x_q, sd, prefix + ".q_proj").unflatten(-1, (H, -1)).transpose(1, 2)
+        k = linear(x_kv, sd, prefix + ".k_proj").unflatten(-1, (H, -1)).transpose(1, 2)
+        v = linear(x_kv, sd, prefix + ".v_proj").unflatten(-1, (H, -1)).transpose(1, 2)
+        if use_rope:
+            start = cache.step_nr if cache is not None else 0
+            q = rope(q, start, tc.rope_theta)
+            k = rope(k, start, tc.rope_theta)
+        if cache is not None:
+            k, v = cache.append(layer, k, v)
+        o = sdpa(q, k, v, key_lens, mask)
+        o = o.transpose(1, 2).flatten(2, 3)
+        return linear(o, sd, prefix + ".output_proj")
+
+    def _ffn(self, prefix: str, tc: TowerConfig, x: Tensor) -> Tensor:
+        sd = self.sd
+        if tc.use_swiglu:   # fairseq2 GLUFeedForwardNetwork: output(inner(x) * silu(gate(x)))
+            return linear(linear(x, sd, prefix + ".inner_proj") * F.silu(linear(x, sd, prefix + ".gate_proj")),
+                          sd, prefix + ".output_proj")
+        assert tc.activation == "relu"
+        return linear(F.relu(linear(x, sd, prefix + ".inner_proj")), sd, prefix + ".output_proj")
+
+    # -- contextualizer (builder.py:161-191)
+    def encode(self, x_norm: Tensor, cache: Optional[KVCache] = None) -> Tensor:
+        cfg, sd, tc = self.cfg, self.sd, self.cfg.context
+        S = x_norm.shape[1]
+        start = cache.step_nr if cache is not None else 0
+        x = linear(x_norm, sd, "encoder_frontend.pre_linear")                # frontend.py:139
+        if tc.pos == "learned":                                             # frontend.py:141-147
+            x = x + sd["encoder_frontend.pos_encoder.weight"][start:start + S]
+        mask = causal_mask(S, start + S)                                     # decoder.py:145-152
+        for i in range(tc.num_layers):
+            p = f"context_encoder.layers.{i}"
+            h = norm(x, sd, p + ".self_attn_layer_norm", tc.norm, cfg.norm_eps)
+            x = x + self._mha(p + ".self_attn", tc, h, h, mask=mask, cache=cache, layer=i,
+                              use_rope=(tc.pos == "rope"))                   # decoder.py:55-88
+            h = norm(x, sd, p + ".ffn_layer_norm", tc.norm, cfg.norm_eps)
+            x = x + self._ffn(p + ".ffn", tc, h)
+        return norm(x, sd, "context_encoder.layer_norm", tc.norm, cfg.norm_eps)   # decoder.py:170-171
+
+    # -- timestep embedding (lcm/nn/timestep_encoder.py:72-122)
+    def embed_time(self, timesteps: Tensor) -> Tensor:
+        half = self.cfg.timestep_freq_dim // 2
+        freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half)
+        args = timesteps.reshape(-1, 1).float() * freqs[None]
+        emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+        h = F.silu(linear(emb, self.sd, "denoiser.embed_time.fc1"))
+        h = linear(h, self.sd, "denoiser.embed_time.fc2")
+        return h.view(*timesteps.shape, self.cfg.model_dim)
+
+    # -- denoiser (lcm_denoiser.py:152-251, 388-546)
+    def denoise(self, latents: Tensor, timesteps: Tensor, context: Tensor,
+                ctx_lens: Optional[Tensor] = None) -> Tensor:
+        """latents (N,1,D), timesteps (N,1) long, context (N,t,d); ctx_lens (N,) visible context
+        length per row or None.  Inference path: diagonal self mask, no cross mask, key padding
+        from ctx_lens shifted by the prepended zero vector."""
+        cfg, sd, tc = self.cfg, self.sd, self.cfg.denoiser
+        emb_t = self.embed_time(timesteps)                                           # :184
+        cond = torch.cat([torch.zeros_like(context[:, 0:1]), context], dim=1)        # :193-199
+        key_lens = None if ctx_lens is None else ctx_lens + 1                        # :201-206
+        x = linear(latents, sd, "denoiser.initial_proj.fc")                          # :209
+        S = x.shape[1]
+        self_mask = torch.eye(S).log()                                               # attention_masks.py:110-113
+        for i in range(tc.num_layers):
+            p = f"denoiser.layers.{i}"
+            mod = linear(F.silu(emb_t), sd, p + ".modulator.fc")                     # :60-64
+            m_san, m_x, m_ffn = mod.chunk(3, dim=-1)
+            # self attention block (:431-473)
+            shift, scale, gate = m_san.chunk(3, dim=-1)
+            h = norm(x, sd, p + ".self_attn_layer_norm", tc.norm, cfg.norm_eps) * (1 + scale) + shift
+            x = x + gate * self._mha(p + ".self_attn", tc, h, h, mask=self_mask, use_rope=(tc.pos == "rope"))
+            # cross attention block (:475-521)
+            shift, scale, gate = m_x.chunk(3, dim=-1)
+            h = norm(x, sd, p + ".cross_attention_layer_norm", tc.norm, cfg.norm_eps) * (1 + scale) + shift
+            x = x + gate * self._mha(p + ".cross_attention", tc, h, cond, key_lens=key_lens,
+                                     use_rope=False)
+            # ffn block (:523-546)
+            shift, scale, gate = m_ffn.chunk(3, dim=-1)
+            h = norm(x, sd, p + ".ffn_layer_norm", tc.norm, cfg.norm_eps) * (1 + scale) + shift
+            x = x + gate * self._ffn(p + ".ffn", tc, h)
+        x = norm(x, sd, "denoiser.layer_norm", tc.norm, cfg.norm_eps)                # :243-244
+        return linear(x, sd, "denoiser.final_proj.fc")                               # :249
+
+    # -- generation-time set-up (builder.py:215-242)
+    def prep_for_denoising(self, opt) -> None:
+        self.guidance_scale = opt.guidance_scale
+        self.guidance_rescale = opt.guidance_rescale
+        self.initial_noise_scale = opt.initial_noise_scale
+        self.clip_noise = opt.clip_noise
+        self.ddim_eta = opt.ddim_eta
+        self.epsilon_scaling = opt.epsilon_scaling
+        self.do_cfg = self.guidance_scale != 1.0
+        self.scheduler.set_timesteps(opt.inference_timesteps)
+        self.scheduler.init_noise_sigma = self.initial_noise_scale
+        if opt.thresholding:
+            self.scheduler.cfg.thresholding = True
+            self.scheduler.cfg.dynamic_thresholding_ratio = opt.dynamic_thresholding_ratio
+            self.scheduler.cfg.sample_max_value = opt.sample_max_value
+
+    def initial_latents(self, noise: Tensor) -> Tensor:
+        """builder.py:244-260 with the N(0,1) draw supplied by the caller: scale by sigma, clip."""
+        lat = noise.float() * self.scheduler.init_noise_sigma
+        return lat.clip(-self.clip_noise, self.clip_noise)
+
+    def apply_cfg(self, eps: Tensor) -> Tensor:
+        # builder.py:463-488 (torch.std default: unbiased)
+        c, u = eps.chunk(2)
+        g = u + self.guidance_scale * (c - u)
+        std_pos = c.std(dim=-1, keepdim=True)
+        std_cfg = g.std(dim=-1, keepdim=True)
+        factor = self.guidance_rescale * (std_pos / std_cfg) + (1 - self.guidance_rescale)
+        return factor * g
+
+    def predict_next_sentence(self, x: Tensor, context: Tensor, cache: KVCache, noise: Tensor,
+                              trace: Optional[List] = None) -> Tuple[Tensor, Tensor]:
+        """x (B,1,D) raw SONAR embeddings, context (B,t,d) -> (next embedding (B,1,D), new context).
+        builder.py:262-338 (no guidance) and :340-461 (classifier-free guidance).  `noise` (B,1,D)
+        replaces the in-function torch.randn; `trace`, if given, collects per-step latents."""
+        sch = self.scheduler
+        new_ctx = self.encode(self.normalize(x), cache)
+        cache.increment_step_nr(1)
+        context = torch.cat((context, new_ctx), dim=1)
+        latents = self.initial_latents(noise)
+        B = x.shape[0]
+        if not self.do_cfg:
+            for t in sch.timesteps.tolist():
+                ts = torch.full((B, 1), t, dtype=torch.long)
+                out = self.denoise(latents, ts, context)
+                prev, x0 = sch.step(out, t, latents, eta=self.ddim_eta, epsilon_scaling=self.epsilon_scaling)
+                latents = prev.clip(-self.clip_noise, self.clip_noise)
+                if trace is not None:
+                    trace.append((t, latents.clone(), x0.clone()))
+            return self.denormalize(x0), context
+
+        t_len = context.shape[1]
+        ctx2 = torch.cat((context, torch.zeros_like(context)), dim=0)                 # :378-381
+        lens2 = torch.cat((torch.full((B,), t_len), torch.zeros(B, dtype=torch.long)))
+        for t in sch.timesteps.tolist():
+            is_max = t == sch.num_train_steps - 1                                     # :385-387
+            inp = torch.cat([latents, latents], dim=0)
+            ts = torch.full((2 * B, 1), t, dtype=torch.long)
+            out = self.denoise(inp, ts, ctx2, lens2)
+            if is_max:                                                                # :404-419
+                prev, x0 = sch.step(out.chunk(2)[0], t, latents, eta=self.ddim_eta,
+                                    epsilon_scaling=self.epsilon_scaling)
+            else:                                                                     # :420-449
+                eps = sch.get_epsilon(out, inp, t)
+                eps = self.apply_cfg(eps)
+                prev, x0 = sch.step(eps, t, latents, eta=self.ddim_eta,
+                                    epsilon_scaling=self.epsilon_scaling, prediction_type="epsilon")
+            latents = prev.clip(-self.clip_noise, self.clip_noise)
+            if trace is not None:
+                trace.append((t, latents.clone(), x0.clone()))
+        # the reference returns the doubled context; the generator keeps only the conditional half
+        # (generator.py:442-448), which is what is returned here.
+        return self.denormalize(x0), context

@@ -1,0 +1,102 @@
+"""End-to-end parity of the HIP generation path against the CPU oracle on identical seeded
+weights, prompts and host-supplied noise.
+
+Tolerances (BASELINE north star): fp32 -- max-abs <= 1e-3 (in normalizer units, i.e. the space
+the model works in) and per-embedding cosine >= 0.9999; bf16 -- cosine >= 0.999.
+"""
+
+import pytest
+import torch
+
+from parity_utils import DEFAULT_OPTS, compare, make_problem, run_hip, run_oracle
+
+pytestmark = pytest.mark.gpu
+
+FP32_MAX_ABS, FP32_COS, BF16_COS = 1e-3, 0.9999, 0.999
+
+
+def test_toy_fp32_config1():
+    """BASELINE config 1: toy arch, 8 docs x (4 prompt + 12 generated), 10 DDIM steps, CFG."""
+    arch = "toy_two_tower_diffusion_lcm"
+    cfg, sd, x, nz = make_problem(arch, 8, 4, 12)
+    opts = dict(DEFAULT_OPTS, inference_timesteps=10)
+    ref = run_oracle(cfg, sd, x, nz, 12, opts)
+    out, _ = run_hip(arch, sd, x, nz, 12, opts)
+    worst, cos = compare(out.hypotheses, ref, sd, start=4)
+    assert worst <= FP32_MAX_ABS and cos >= FP32_COS, (worst, cos)
+    assert all(h[0].seq.shape == (16, 1024) for h in out.hypotheses)
+
+
+@pytest.mark.parametrize("guidance", [1.0, 3.0])
+def test_mini_fp32(guidance):
+    """1.6B-style blocks (RMSNorm, RoPE, SwiGLU, out-proj bias, T=100 -> 50 executed steps)."""
+    arch = "mini_two_tower_diffusion_lcm"
+    cfg, sd, x, nz = make_problem(arch, 5, 3, 4)
+    opts = dict(DEFAULT_OPTS, inference_timesteps=40, guidance_scale=guidance)
+    ref = run_oracle(cfg, sd, x, nz, 4, opts)
+    out, _ = run_hip(arch, sd, x, nz, 4, opts)
+    worst, cos = compare(out.hypotheses, ref, sd, start=3)
+    assert worst <= FP32_MAX_ABS and cos >= FP32_COS, (worst, cos)
+
+
+def test_mini_bf16():
+    arch = "mini_two_tower_diffusion_lcm"
+    cfg, sd, x, nz = make_problem(arch, 6, 3, 4)
+    opts = dict(DEFAULT_OPTS, inference_timesteps=40)
+    # the oracle sees the bf16-rounded weights and prompts, in fp32 arithmetic
+    sd16 = {k: v.bfloat16().float() for k, v in sd.items()}
+    ref = run_oracle(cfg, sd16, x.bfloat16().float(), nz, 4, opts)
+    out, _ = run_hip(arch, sd, x, nz, 4, opts, dtype=torch.bfloat16)
+    worst, cos = compare(out.hypotheses, ref, sd16, start=3)
+    assert cos >= BF16_COS, (worst, cos)
+
+
+def test_ragged_prompts_and_early_finish():
+    """Ragged prompts: rows still inside their prompt keep the prompt embedding, documents finish at
+    different steps (prompt_len + max_gen_len) and leave the batch."""
+    arch = "toy_two_tower_diffusion_lcm"
+    lens = [2, 5, 3, 5]
+    cfg, sd, x, nz = make_problem(arch, 4, 5, 3, prompt_lens=lens)
+    opts = dict(DEFAULT_OPTS, inference_timesteps=5)
+    ref = run_oracle(cfg, sd, x, nz, 3, opts, prompt_lens=lens)
+    out, _ = run_hip(arch, sd, x, nz, 3, opts, prompt_lens=lens)
+    for i, n in enumerate(lens):
+        assert out.hypotheses[i][0].seq.shape[0] == n + 3 == ref[i][0].seq.shape[0]
+    worst, cos = compare(out.hypotheses, ref, sd)
+    assert worst <= FP32_MAX_ABS and cos >= FP32_COS, (worst, cos)
+
+
+def test_eos_stop_matches_oracle():
+    """An EOS vector equal to document 1's second generated sentence stops that document there."""
+    arch = "toy_two_tower_diffusion_lcm"
+    cfg, sd, x, nz = make_problem(arch, 3, 3, 5)
+    opts = dict(DEFAULT_OPTS, inference_timesteps=5)
+    free = run_oracle(cfg, sd, x, nz, 5, opts)
+    eos = free[1][0].seq[4].clone()
+    opts_eos = dict(opts, eos_threshold=0.999, trim_hypotheses=True)
+    ref = run_oracle(cfg, sd, x, nz, 5, opts_eos, eos_vec=eos)
+    out, _ = run_hip(arch, sd, x, nz, 5, opts_eos, eos_vec=eos)
+    assert [h[0].seq.shape[0] for h in out.hypotheses] == [h[0].seq.shape[0] for h in ref]
+    assert ref[1][0].seq.shape[0] == 4          # stopped at step 4, EOS trimmed
+    worst, cos = compare(out.hypotheses, ref, sd)
+    assert worst <= FP32_MAX_ABS and cos >= FP32_COS, (worst, cos)
+
+
+def test_batch_of_one_equals_batch(monkeypatch):
+    """The reference's batched-vs-single invariant (tests/units/inference/
+    test_base_lcm_batched_inference.py:21-96) on the HIP path: a document generated alone equals
+    the same document generated inside a batch (noise indexed by document)."""
+    arch = "mini_two_tower_diffusion_lcm"
+    cfg, sd, x, nz = make_problem(arch, 3, 3, 3)
+    opts = dict(DEFAULT_OPTS, inference_timesteps=10)
+    out, model = run_hip(arch, sd, x, nz, 3, opts)
+    for i in range(3):
+        single, _ = run_hip(arch, sd, x[i:i + 1], nz[:, i:i + 1], 3, opts, model=model)
+        a, b = single.hypotheses[0][0].seq, out.hypotheses[i][0].seq
+        assert (a - b).abs().max() <= 1e-6 * max(1.0, float(b.abs().max()))
+
+
+def test_no_cpu_fallback():
+    from lcm.models.two_tower_diffusion_lcm import create_two_tower_diffusion_lcm_model, lcm_archs
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        create_two_tower_diffusion_lcm_model(lcm_archs.get_config("toy_two_tower_diffusion_lcm"), device="cpu")

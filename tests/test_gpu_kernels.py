@@ -1,0 +1,205 @@
+"""Single-kernel parity through the C ABI: each HIP kernel against the oracle's statement of the
+same operation (fp32: max-abs tolerances written at each check; bf16: against the fp32 result
+of the bf16-rounded inputs)."""
+
+import ctypes as C
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    assert torch.cuda.is_available()
+    from lcm import _hip
+    return _hip
+
+
+def _st(hip):
+    return hip.stream_ptr(torch.device("cuda:0"))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows", [1, 7, 300])
+def test_normalizer_roundtrip(hip, normalizer, dtype, rows):
+    torch.manual_seed(0)
+    c, s = normalizer["center"].cuda().to(dtype), normalizer["scale"].cuda().to(dtype)
+    x = (normalizer["center"] + normalizer["scale"] * torch.randn(rows, 1024)).cuda().to(dtype)
+    y = torch.empty_like(x)
+    hip.check(hip.lib.lcmhip_normalize(hip.ptr(x), hip.ptr(c), hip.ptr(s), None, None, hip.ptr(y), rows, 1024,
+                                       hip.dtype_code(dtype), _st(hip)))
+    ref = (x.float() - c.float()) / s.float()
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert (y.float() - ref).abs().max() <= tol * max(1.0, float(ref.abs().max()))
+    z = torch.empty_like(x)
+    hip.check(hip.lib.lcmhip_denormalize(hip.ptr(y), hip.ptr(c), hip.ptr(s), None, None, hip.ptr(z), rows, 1024,
+                                         hip.dtype_code(dtype), _st(hip)))
+    ref_z = y.float() * s.float() + c.float()
+    assert (z.float() - ref_z).abs().max() <= (1e-6 if dtype == torch.float32 else 5e-4)
+
+
+def test_normalizer_clip(hip, normalizer):
+    c, s = normalizer["center"].cuda(), normalizer["scale"].cuda()
+    x = (normalizer["center"] + 3 * normalizer["scale"] * torch.randn(5, 1024)).cuda()
+    lo, hi = torch.full((1024,), -1.5).cuda(), torch.full((1024,), 2.0).cuda()
+    y = torch.empty_like(x)
+    hip.check(hip.lib.lcmhip_normalize(hip.ptr(x), hip.ptr(c), hip.ptr(s), hip.ptr(lo), hip.ptr(hi), hip.ptr(y), 5, 1024, 0, _st(hip)))
+    ref = torch.clamp((x - c) / s, min=lo, max=hi)
+    assert (y - ref).abs().max() <= 1e-5
+    z = torch.empty_like(x)
+    big = 3 * torch.randn(5, 1024).cuda()
+    hip.check(hip.lib.lcmhip_denormalize(hip.ptr(big), hip.ptr(c), hip.ptr(s), hip.ptr(lo), hip.ptr(hi), hip.ptr(z), 5, 1024, 0, _st(hip)))
+    assert (z - (torch.clamp(big, min=lo, max=hi) * s + c)).abs().max() <= 1e-7
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("kind", ["rms", "standard"])
+@pytest.mark.parametrize("dim", [256, 1024, 2048])
+def test_norm_modulate(hip, dtype, kind, dim):
+    from oracle.model import norm as oracle_norm
+    torch.manual_seed(1)
+    rows = 9
+    x = (torch.randn(rows, dim) * 3 + 0.5).cuda()
+    w = (1 + 0.1 * torch.randn(dim)).cuda().to(dtype)
+    b = (0.1 * torch.randn(dim)).cuda().to(dtype) if kind == "standard" else None
+    shift, scale = (0.3 * torch.randn(dim)).cuda(), (0.3 * torch.randn(dim)).cuda()
+    sd = {"n.weight": w.float().cpu()}
+    if b is not None:
+        sd["n.bias"] = b.float().cpu()
+    for mod in (False, True):
+        y = torch.empty(rows, dim, device="cuda", dtype=dtype)
+        hip.check(hip.lib.lcmhip_norm_modulate(hip.ptr(x), hip.ptr(w), hip.ptr(b), hip.ptr(shift) if mod else None,
+                                               hip.ptr(scale) if mod else None, hip.ptr(y), rows, dim,
+                                               1 if kind == "rms" else 0, 1e-5, hip.dtype_code(dtype), _st(hip)))
+        ref = oracle_norm(x.cpu(), sd, "n", kind, 1e-5)
+        if mod:
+            ref = ref * (1 + scale.cpu()) + shift.cpu()
+        tol = 2e-5 if dtype == torch.float32 else 4e-2
+        assert (y.float().cpu() - ref).abs().max() <= tol, (kind, dim, mod)
+
+
+def _gemm(hip, A, W, W2, bias, bias2, gate, out, epi):
+    M, K = A.shape
+    N = W.shape[0]
+    hip.check(hip.lib.lcmhip_gemm(hip.ptr(A), A.stride(0), hip.ptr(W), hip.ptr(W2), hip.ptr(bias), hip.ptr(bias2),
+                                  hip.ptr(gate), hip.ptr(out), out.stride(0), M, N, K, epi, hip.dtype_code(A.dtype), _st(hip)))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M", [1, 17, 50, 64, 100, 128, 200])
+@pytest.mark.parametrize("N,K", [(256, 256), (1024, 2048), (768, 256), (2048, 5632)])
+def test_gemm_epilogues(hip, dtype, M, N, K):
+    torch.manual_seed(M * 1000 + N + K)
+    A = torch.randn(M, K).cuda().to(dtype)
+    W = (torch.randn(N, K) / math.sqrt(K)).cuda().to(dtype)
+    W2 = (torch.randn(N, K) / math.sqrt(K)).cuda().to(dtype)
+    b = torch.randn(N).cuda().to(dtype)
+    b2 = torch.randn(N).cuda().to(dtype)
+    gate = torch.randn(N).cuda()
+    Af, Wf, W2f, bf, b2f = (t.double().cpu() for t in (A, W, W2, b, b2))
+    lin = Af @ Wf.T + bf
+    tol = 2e-4 if dtype == torch.float32 else 3e-2       # bf16: output rounding of O(1) values
+    # STORE (asymmetric data catches a transposed fragment map)
+    out = torch.empty(M, N, device="cuda", dtype=dtype)
+    _gemm(hip, A, W, None, b, None, None, out, hip.EPI_STORE)
+    assert (out.double().cpu() - lin).abs().max() <= tol * max(1.0, float(lin.abs().max()))
+    # STORE_F32 without bias
+    out32 = torch.empty(M, N, device="cuda")
+    _gemm(hip, A, W, None, None, None, None, out32, hip.EPI_STORE_F32)
+    assert (out32.double().cpu() - (lin - bf)).abs().max() <= (2e-4 if dtype == torch.float32 else 2e-3) * max(1.0, float(lin.abs().max()))
+    # RELU
+    _gemm(hip, A, W, None, b, None, None, out, hip.EPI_RELU)
+    assert (out.double().cpu() - lin.clamp(min=0)).abs().max() <= tol * max(1.0, float(lin.abs().max()))
+    # SWIGLU: (inner) * silu(gate)
+    _gemm(hip, A, W, W2, b, b2, None, out, hip.EPI_SWIGLU)
+    ref = (Af @ W2f.T + b2f) * torch.nn.functional.silu(lin)
+    assert (out.double().cpu() - ref).abs().max() <= tol * max(1.0, float(ref.abs().max()))
+    # RESID with and without gate
+    res0 = torch.randn(M, N).cuda()
+    res = res0.clone()
+    _gemm(hip, A, W, None, b, None, gate, res, hip.EPI_RESID)
+    ref = res0.double().cpu() + gate.double().cpu() * lin
+    assert (res.double().cpu() - ref).abs().max() <= (2e-4 if dtype == torch.float32 else 2e-3) * max(1.0, float(ref.abs().max()))
+    res = res0.clone()
+    _gemm(hip, A, W, None, None, None, None, res, hip.EPI_RESID)
+    ref = res0.double().cpu() + (lin - bf)
+    assert (res.double().cpu() - ref).abs().max() <= (2e-4 if dtype == torch.float32 else 2e-3) * max(1.0, float(ref.abs().max()))
+
+
+def test_gemm_identity_asymmetric(hip):
+    """A = I against an asymmetric integer W: exact in bf16, exposes any row/col swap."""
+    K = N = 256
+    A = torch.eye(64, K).cuda().to(torch.bfloat16)
+    W = (torch.arange(N).view(N, 1) % 7 - 3 + 2 * (torch.arange(K).view(1, K) % 5)).float().cuda().to(torch.bfloat16)
+    out = torch.empty(64, N, device="cuda")
+    _gemm(hip, A, W, None, None, None, None, out, hip.EPI_STORE_F32)
+    assert torch.equal(out.cpu(), W.float().cpu().T[:64])
+
+
+def test_gemm_rejects_bad_shapes(hip):
+    A = torch.zeros(4, 100, device="cuda")
+    W = torch.zeros(64, 100, device="cuda")
+    out = torch.zeros(4, 64, device="cuda")
+    with pytest.raises(RuntimeError, match="128-byte"):
+        _gemm(hip, A, W, None, None, None, None, out, hip.EPI_STORE)
+
+
+@pytest.mark.parametrize("mode", ["plain_sample", "plain_epsilon", "cfg"])
+def test_ddim_cfg_step(hip, mode):
+    import oracle
+    from oracle.archs import SchedulerConfig
+    torch.manual_seed(3)
+    rows, dim = 5, 1024
+    sch = oracle.DDIMSchedule(SchedulerConfig(num_train_steps=100))
+    sch.set_timesteps(40)
+    t = 57
+    x = torch.randn(rows, 1, dim) * 0.8
+    oc, ou = torch.randn(rows, 1, dim), torch.randn(rows, 1, dim)
+    a_t, a_prev = sch._alphas(t)
+    p = hip.DenoiseParams(guidance_scale=3.0, guidance_rescale=0.7, ddim_eta=0.0, epsilon_scaling=0.0, clip_noise=1.5,
+                          init_noise_sigma=1.0, prediction_type=hip.PRED["epsilon" if mode == "plain_epsilon" else "sample"],
+                          clip_sample=0, clip_sample_range=1.0)
+    if mode == "cfg":
+        class M:  # the oracle's guidance needs only these attributes
+            guidance_scale, guidance_rescale = 3.0, 0.7
+        eps = sch.get_epsilon(torch.cat([oc, ou]), torch.cat([x, x]), t)
+        eps = oracle.OracleTwoTower.apply_cfg(M, eps)
+        prev, x0 = sch.step(eps, t, x, prediction_type="epsilon")
+    else:
+        prev, x0 = sch.step(oc, t, x, prediction_type="epsilon" if mode == "plain_epsilon" else "sample")
+    prev = prev.clip(-1.5, 1.5)
+    xg, ocg, oug = x.reshape(rows, dim).cuda(), oc.reshape(rows, dim).cuda(), ou.reshape(rows, dim).cuda()
+    pg, zg = torch.empty_like(xg), torch.empty_like(xg)
+    hip.check(hip.lib.lcmhip_ddim_cfg_step(hip.ptr(xg), hip.ptr(ocg), hip.ptr(oug) if mode == "cfg" else None, hip.ptr(pg),
+                                           hip.ptr(zg), rows, dim, float(a_t), float(a_prev), C.byref(p), _st(hip)))
+    assert (pg.cpu() - prev.reshape(rows, dim)).abs().max() <= 2e-5
+    assert (zg.cpu() - x0.reshape(rows, dim)).abs().max() <= 2e-5 * max(1.0, float(x0.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("causal,s,base", [(0, 1, 1), (0, 1, 137), (1, 1, 40), (1, 7, 0), (1, 5, 66)])
+def test_attention(hip, dtype, causal, s, base):
+    from oracle.model import sdpa
+    torch.manual_seed(5)
+    n_docs, H, cap = 3, 8, 160
+    d = H * 128
+    kc = torch.randn(4, cap, d).cuda().to(dtype)       # 4 slots, documents mapped to slots 2, 0, 3
+    vc = torch.randn(4, cap, d).cuda().to(dtype)
+    slot = torch.tensor([2, 0, 3], dtype=torch.int32).cuda()
+    q = (2 * torch.randn(n_docs * s, d)).cuda().to(dtype)
+    out = torch.empty_like(q)
+    hip.check(hip.lib.lcmhip_attention(hip.ptr(q), hip.ptr(kc), hip.ptr(vc), hip.ptr(slot), hip.ptr(out), n_docs, s, H, cap,
+                                       base, causal, hip.dtype_code(dtype), _st(hip)))
+    nk = base + (s if causal else 0)
+    qh = q.float().cpu().view(n_docs, s, H, 128).transpose(1, 2)
+    kh = kc.float().cpu()[[2, 0, 3], :nk].view(n_docs, nk, H, 128).transpose(1, 2)
+    vh = vc.float().cpu()[[2, 0, 3], :nk].view(n_docs, nk, H, 128).transpose(1, 2)
+    mask = None
+    if causal and s > 1:
+        mask = torch.full((nk, nk), float("-inf")).triu(1)[nk - s:]
+    ref = sdpa(qh, kh, vh, None, mask).transpose(1, 2).reshape(n_docs * s, d)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert (out.float().cpu() - ref).abs().max() <= tol
