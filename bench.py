@@ -1,0 +1,216 @@
+#!/usr/bin/env python
+"""Headline benchmark: sentence-embeddings generated/s, 1.6B two-tower LCM, 40 diffusion steps.
+
+One "step" is one full `TwoTowerDiffusionLCMGenerator(batch)` call on the workload of BASELINE
+config 3: 64 documents per GPU, 8 prompt sentences, 128 generated sentences, 40 requested DDIM
+steps (50 executed, because the reference's integer `arange` truncates the step of the trailing
+schedule), classifier-free guidance w=3 / rescale 0.7, bf16 weights, synthetic prompts, seeded
+random-init weights and host-supplied noise indexed by global document id.  With N > 1 ranks
+every rank generates its own 64 documents (weak scaling, no collective in the loop) and the
+outputs are all-gathered once at the end (RCCL), inside the timed region.
+
+Rank 0 prints ONE JSON line with the whole-job throughput plus
+  roofline     -- the dominant kernel (weight-streaming GEMM of the denoiser FFN up-projection),
+                  timed live with HIP events on the generation stream in an extra, untimed pass;
+  cpu_baseline -- the CPU oracle (a restatement of the reference algorithm) timed on this box's
+                  host cores on a bounded sample of the same workload.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak
+ARCH = "two_tower_diffusion_lcm_1_6B"
+OPTS = dict(guidance_scale=3.0, guidance_rescale=0.7, initial_noise_scale=0.6, inference_timesteps=40,
+            eos_threshold=None, max_seq_len=128)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=64, help="documents per GPU")
+    ap.add_argument("--prompt-len", type=int, default=8)
+    ap.add_argument("--gen-len", type=int, default=128)
+    ap.add_argument("--arch", default=ARCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-sentence-steps", type=int, default=1)
+    return ap.parse_args()
+
+
+def make_noise(gen_len, batch, first_doc, device):
+    """N(0,1) draws indexed by GLOBAL document id: independent of how documents are sharded."""
+    out = torch.empty(gen_len, batch, 1024, device=device)
+    for i in range(batch):
+        g = torch.Generator(device=device).manual_seed(4321 + first_doc + i)
+        out[:, i] = torch.randn(gen_len, 1024, generator=g, device=device)
+    return out
+
+
+def make_prompts(model, batch, prompt_len, first_doc, device):
+    out = torch.empty(batch, prompt_len, 1024, device=device)
+    c, s = model.sonar_normalizer.center.float(), model.sonar_normalizer.scale.float()
+    for i in range(batch):
+        g = torch.Generator(device=device).manual_seed(1234 + first_doc + i)
+        out[i] = c + s * torch.randn(prompt_len, 1024, generator=g, device=device)
+    return out
+
+
+def roofline_pass(model, gen_cls, opt_cls, batch, prompt_len, gen_len, device):
+    """Untimed extra pass with per-launch HIP events on the generation stream (mid-generation
+    context length, two sentence steps).  Returns (roofline dict, per-kernel table)."""
+    from lcm.datasets.batch import EmbeddingsBatch
+
+    mid = prompt_len + gen_len // 2
+    gen = gen_cls(model, opt_cls(**OPTS))
+    x = make_prompts(model, batch, mid, 0, device).to(model.dtype)
+    nz = make_noise(2, batch, 0, device)
+    # the session is created lazily by the first call: run once plain, then once with events on
+    gen(EmbeddingsBatch(x, None), max_gen_len=2, noise=nz)
+    sess = model._session_pool[0]
+    sess.profile_enable(True)
+    gen(EmbeddingsBatch(x, None), max_gen_len=2, noise=nz)
+    rows = sess.profile()
+    sess.profile_enable(False)
+    table = {}
+    for r in rows:
+        if r["launches"] == 0:
+            continue
+        avg_us = 1e3 * r["total_ms"] / r["launches"]
+        table[r["name"]] = dict(launches=r["launches"], total_ms=round(r["total_ms"], 3), avg_us=round(avg_us, 3),
+                                gbps=round(r["bytes"] / r["total_ms"] / 1e6, 1) if r["total_ms"] > 0 else None,
+                                tflops=round(r["flops"] / r["total_ms"] / 1e9, 2) if r["total_ms"] > 0 else None)
+    dom = max((r for r in rows if r["name"].startswith("den.")), key=lambda r: r["total_ms"])
+    achieved = dom["bytes"] / dom["total_ms"] / 1e6      # GB/s
+    roof = dict(bound="hbm", kernel=dom["name"], achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                avg_launch_us=round(1e3 * dom["total_ms"] / dom["launches"], 3),
+                bytes_per_launch=round(dom["bytes"] / dom["launches"]))
+    return roof, table
+
+
+def cpu_baseline(batch, prompt_len, sentence_steps):
+    """The oracle (reference algorithm, PyTorch-CPU fp32) on the same workload shape, bounded to
+    `sentence_steps` generated sentences per document after the prefill."""
+    import oracle
+    from oracle.weights import synthetic_noise, synthetic_prompts
+
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    cfg = oracle.get_arch(ARCH)
+    sd = oracle.init_state_dict(cfg, seed=0, mod_gain=10.0)
+    model = oracle.OracleTwoTower(cfg, sd)
+    opts = {k: v for k, v in OPTS.items()}
+    gen = oracle.OracleGenerator(model, oracle.GenOptions(**opts))
+    x = synthetic_prompts(oracle.load_dummy_normalizer(), batch, prompt_len)
+    nz = synthetic_noise(sentence_steps, batch)
+    t0 = time.perf_counter()
+    gen(x, max_gen_len=sentence_steps, noise=nz)
+    dt = time.perf_counter() - t0
+    return dict(value=round(batch * sentence_steps / dt, 3), unit="sentence-embeddings/s", cores=cores, kind="port",
+                sample=f"oracle (PyTorch-CPU fp32 restatement of the reference), {batch} docs x {prompt_len} prompt, "
+                       f"{sentence_steps} generated sentence(s) per doc incl. prefill, 50 executed DDIM steps + CFG; "
+                       f"{dt:.1f} s wall")
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    from lcm.datasets.batch import EmbeddingsBatch
+    from lcm.inference.two_tower_diffusion_lcm import DiffusionLCMGeneratorOptions, TwoTowerDiffusionLCMGenerator
+    from lcm.models.two_tower_diffusion_lcm import create_two_tower_diffusion_lcm_model, lcm_archs
+    from lcm.utils.card_utils import load_model_from_card
+    from lcm.utils.distributed import all_gather_generations
+
+    B, P, G = args.batch, args.prompt_len, args.gen_len
+    opts = dict(OPTS, max_seq_len=max(G, OPTS["max_seq_len"]))
+    model = create_two_tower_diffusion_lcm_model(lcm_archs.get_config(args.arch), device=device, dtype=torch.bfloat16, seed=0)
+    model.init_parameters(seed=0, modulator_std=0.2)       # non-zero adaLN modulators: every layer does real work
+    normalizer = load_model_from_card("dummy_sonar_normalizer", device=device, dtype=torch.bfloat16)
+    model.sonar_normalizer.load_state_dict(normalizer.state_dict())
+    gen = TwoTowerDiffusionLCMGenerator(model, DiffusionLCMGeneratorOptions(**opts))
+
+    first_doc = rank * B
+    prompts = make_prompts(model, B, P, first_doc, device).to(model.dtype)
+    noise = make_noise(G, B, first_doc, device)
+    stream = torch.cuda.Stream(device)
+
+    def one_step():
+        with torch.cuda.stream(stream):
+            out = gen(EmbeddingsBatch(prompts, None), max_gen_len=G, noise=noise)
+            seqs = torch.stack([h[0].seq for h in out.hypotheses])           # (B, P+G, D)
+            lens = torch.tensor([h[0].seq.shape[0] for h in out.hypotheses], device=device, dtype=torch.int32)
+            if distributed:
+                seqs, lens = all_gather_generations(seqs, lens)
+        return seqs, lens
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        one_step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        seqs, lens = one_step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    generated = int((lens.to(torch.int64) - P).sum().item())                 # all ranks' documents after the gather
+    assert generated == world * B * G, (generated, world, B, G)
+    assert torch.isfinite(seqs.float()).all()
+
+    result = None
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        result = {
+            "metric": "sentence-embeddings generated/s, 1.6B two-tower LCM, 40 diffusion steps",
+            "value": round(generated / (elapsed / args.steps), 2), "unit": "sentence-embeddings/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"BASELINE config 3: {args.arch}, random-init, {B} docs/GPU x {P} prompt + {G} generated "
+                                   f"sentences, 40 requested = 50 executed DDIM steps, CFG w=3 rescale=0.7",
+                       "global_batch": world * B, "prompt_len": P, "gen_len": G, "executed_ddim_steps": 50,
+                       "parallelism": f"dp{world} by document, one all-gather of outputs"},
+        }
+    if rank == 0 and world == 1 and not args.no_roofline:
+        with torch.cuda.stream(stream):
+            roof, table = roofline_pass(model, TwoTowerDiffusionLCMGenerator, DiffusionLCMGeneratorOptions, B, P, G, device)
+        result["roofline"] = roof
+        result["kernels"] = table
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(B, P, args.cpu_sentence_steps)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -147,16 +147,39 @@ struct GemmArgs {
     int dtype;
     // RESID only: rows [M, M + extra_rows) of `out` get gate[n] * extra_const[n] added
     int extra_rows; const float* extra_const;
+    // split-K: fp32 slab [splits][M][N] (optional; without it the K range is never split)
+    float* partial; size_t partial_bytes; int max_splits;
 };
+// C = A W^T with the epilogue applied (split-K + finishing pass when a.partial is given and it pays).
 int launch_gemm(const GemmArgs& a, hipStream_t st);
+// Raw partial products only: slab [*splits][M][N] in a.partial, to be summed by the consumer.
+int launch_gemm_partial(const GemmArgs& a, int* splits, hipStream_t st);
+
+// A product still sitting in a split-K slab, to be folded into the residual stream by the next
+// norm kernel:  x[r] = (init ? 0 : x[r]) + gate * (sum_s slab[s][src(r)] + bias)   for r <  M
+//               x[r] = x[r] + gate * extra_const                                    for r >= M (dup == 0)
+// with src(r) = r, or r - M for the duplicated rows when dup == 1.
+struct Pending {
+    const float* partial = nullptr;
+    int splits = 0;
+    int M = 0;
+    const void* bias = nullptr;       // operand dtype, nullable
+    const float* gate = nullptr;      // fp32, nullable (= 1)
+    const float* extra_const = nullptr;
+    int dup = 0;
+    int init = 0;
+};
 
 int launch_normalize(const void* x, const void* center, const void* scale, const void* cmin, const void* cmax,
                      void* y, int64_t rows, int dim, int dtype, bool inverse, hipStream_t st);
 // fp32 in -> T out, used by the frontend: y = (x - center) / scale with T-typed center/scale.
 int launch_normalize_f32_in(const float* x, const void* center, const void* scale, void* y, int64_t rows, int dim,
                             int dtype, hipStream_t st);
-int launch_norm_modulate(const float* x, const void* w, const void* b, const float* shift, const float* scale,
-                         void* y, int rows, int dim, int norm_kind, float eps, int dtype, hipStream_t st);
+// Rows [0, rows_norm) are normalised (+ modulated) into y; when `pend` is given, rows [0, rows_total)
+// of x first absorb the pending product (x is updated in place).
+int launch_norm_modulate(float* x, const void* w, const void* b, const float* shift, const float* scale,
+                         void* y, int rows_total, int rows_norm, int dim, int norm_kind, float eps, int dtype,
+                         const Pending* pend, hipStream_t st);
 int launch_attention(const void* q, const void* kc, const void* vc, const int32_t* slot_map, void* out, int n_docs,
                      int s, int n_heads, int cap, int base_keys, int causal, int dtype, hipStream_t st);
 

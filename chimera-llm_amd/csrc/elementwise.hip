@@ -110,22 +110,56 @@ int launch_denormalize_f32_out(const float* x0, const void* center, const void* 
 // registers between the statistics pass and the output pass (dim <= 8192).
 // ------------------------------------------------------------------------------------------------
 template <typename T, int KIND>
-__global__ __launch_bounds__(256) void k_norm_modulate(const float* __restrict__ x, const T* __restrict__ w,
+__global__ __launch_bounds__(256) void k_norm_modulate(float* __restrict__ x, const T* __restrict__ w,
                                                        const T* __restrict__ b, const float* __restrict__ shift,
                                                        const float* __restrict__ scale, T* __restrict__ y, int dim,
-                                                       float eps) {
+                                                       int rows_norm, float eps, Pending pd) {
     constexpr int MAXV = 8;  // float4 chunks per lane
     __shared__ float red[4];
     const int row = blockIdx.x;
-    const float* xr = x + (size_t)row * dim;
+    float* xr = x + (size_t)row * dim;
     const int nv = dim / 4;
     float4 v[MAXV];
+    // ---- absorb the pending split-K product into the residual stream
+    const bool has_pending = pd.partial != nullptr;
+    const int src_row = row < pd.M ? row : (pd.dup ? row - pd.M : -1);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = threadIdx.x + i * 256;
+        if (c < nv) {
+            if (has_pending && pd.init) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            else v[i] = *reinterpret_cast<const float4*>(xr + c * 4);
+            if (has_pending) {
+                float4 a;
+                if (src_row >= 0) {
+                    a = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int s = 0; s < pd.splits; ++s) {
+                        const float4 t = *reinterpret_cast<const float4*>(pd.partial + ((size_t)s * pd.M + src_row) * dim + c * 4);
+                        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+                    }
+                    if (pd.bias != nullptr) {
+                        const T* bp = reinterpret_cast<const T*>(pd.bias) + c * 4;
+                        a.x += Elem<T>::load(bp); a.y += Elem<T>::load(bp + 1);
+                        a.z += Elem<T>::load(bp + 2); a.w += Elem<T>::load(bp + 3);
+                    }
+                } else {
+                    a = *reinterpret_cast<const float4*>(pd.extra_const + c * 4);
+                }
+                if (pd.gate != nullptr) {
+                    const float4 g = *reinterpret_cast<const float4*>(pd.gate + c * 4);
+                    a.x *= g.x; a.y *= g.y; a.z *= g.z; a.w *= g.w;
+                }
+                v[i].x += a.x; v[i].y += a.y; v[i].z += a.z; v[i].w += a.w;
+                *reinterpret_cast<float4*>(xr + c * 4) = v[i];
+            }
+        }
+    }
+    if (row >= rows_norm) return;   // uniform per workgroup
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = threadIdx.x + i * 256;
         if (c < nv) {
-            v[i] = *reinterpret_cast<const float4*>(xr + c * 4);
             if (KIND == LCMHIP_NORM_RMS)
                 s += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
             else
@@ -176,15 +210,26 @@ __global__ __launch_bounds__(256) void k_norm_modulate(const float* __restrict__
     }
 }
 
-int launch_norm_modulate(const float* x, const void* w, const void* b, const float* shift, const float* scale,
-                         void* y, int rows, int dim, int norm_kind, float eps, int dtype, hipStream_t st) {
+int launch_norm_modulate(float* x, const void* w, const void* b, const float* shift, const float* scale,
+                         void* y, int rows_total, int rows_norm, int dim, int norm_kind, float eps, int dtype,
+                         const Pending* pend, hipStream_t st) {
     LCM_REQUIRE(dim % 4 == 0 && dim <= 8192, "norm: dim must be a multiple of 4 and <= 8192");
     LCM_REQUIRE((shift == nullptr) == (scale == nullptr), "norm: shift and scale go together");
     LCM_REQUIRE(w != nullptr, "norm: weight required");
+    LCM_REQUIRE(rows_norm <= rows_total, "norm: rows_norm exceeds rows_total");
+    if (rows_total <= 0) return LCMHIP_OK;
+    Pending pd;
+    if (pend) {
+        pd = *pend;
+        LCM_REQUIRE(pd.partial && pd.splits >= 1 && pd.M >= 1, "norm: bad pending product");
+        LCM_REQUIRE(pd.dup ? rows_total <= 2 * pd.M : (rows_total <= pd.M || pd.extra_const != nullptr),
+                    "norm: rows beyond the pending product need a constant");
+    }
+    const int rows = pend ? rows_total : rows_norm;
     if (rows <= 0) return LCMHIP_OK;
 #define LCM_NORM(T, KIND)                                                                                      \
     hipLaunchKernelGGL((k_norm_modulate<T, KIND>), dim3(rows), dim3(256), 0, st, x, (const T*)w, (const T*)b, shift, \
-                       scale, (T*)y, dim, eps)
+                       scale, (T*)y, dim, rows_norm, eps, pd)
     if (dtype == LCMHIP_BF16) {
         if (norm_kind == LCMHIP_NORM_RMS) LCM_NORM(bf16_t, LCMHIP_NORM_RMS); else LCM_NORM(bf16_t, LCMHIP_NORM_LAYERNORM);
     } else if (dtype == LCMHIP_F32) {

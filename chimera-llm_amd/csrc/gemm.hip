@@ -1,14 +1,18 @@
-// C = A * W^T with fused epilogues, for the row counts of sentence-level generation
-// (M = 1 .. a few hundred rows, weights streamed once from HBM).
+// C = A * W^T for the row counts of sentence-level generation (M = 1 .. a few hundred rows): the
+// weights are streamed once from HBM and the job is to keep every CU's memory queue full.
 //
-// Tiling: one workgroup = 4 waves = one BM x BN output tile, K walked in 128-byte slices.  Both
-// operands go through LDS in full 128-byte lines (rows padded to 144 B: conflict-free for the
-// 16-byte fragment reads) so that every global load instruction covers whole cache lines; the
-// next slice is held in registers while the current one feeds the MFMAs (one barrier per slice).
-// MFMA orientation: the WEIGHT rows are the matrix-core A operand and the ACTIVATION rows the B
-// operand, so each lane ends up with 4 consecutive output columns of one output row -- one
-// vector load of bias/gate and one vector store per accumulator.
+// Decomposition: grid = (weight-row tiles, K splits, row tiles).  A workgroup (4 waves) owns a
+// (32*WM rows) x (64*WN weight rows) tile and a contiguous range of 512-byte K chunks.  A whole
+// chunk of both operands -- 24..36 16-byte loads per lane, all issued back to back -- is pulled
+// into registers, written to LDS in full 512-byte rows (+16 B pad: conflict-free 16-byte
+// fragment reads) and consumed by the matrix cores while the next chunk's loads are in flight.
+// With split-K the fp32 partial tiles go to a slab [split][row][col]; they are summed by the
+// consumer (the fused residual+norm kernel, or k_splitk_finish) -- no atomics, deterministic.
+// MFMA orientation: WEIGHT rows are the matrix-core A operand, ACTIVATION rows the B operand, so
+// a lane holds 4 consecutive output columns of one row (vector bias/gate loads, vector stores).
 //   bf16 operands: v_mfma_f32_16x16x32_bf16;  f32 operands: v_mfma_f32_16x16x4_f32 (exact fp32).
+#include <algorithm>
+
 #include "common.h"
 
 namespace lcmhip {
@@ -37,225 +41,356 @@ struct Mma<float> {
     }
 };
 
-constexpr int kSliceBytes = 128;  // bytes of K per tile row per slice
-constexpr int kRowBytes = 144;    // padded LDS row
+constexpr int kChunkBytes = 512;             // bytes of K per tile row per chunk
+constexpr int kRowBytes = kChunkBytes + 16;  // padded LDS row
+constexpr int EPI_PARTIAL = 100;             // internal: raw fp32 partial tile to the split-K slab
 
-template <typename T, int BM, int BN, int EPI>
+template <typename T, int WM, int WN, int EPI>
 __global__ __launch_bounds__(256) void k_gemm(GemmArgs p) {
     constexpr bool DUAL = (EPI == LCMHIP_EPI_SWIGLU);
-    constexpr int R = BM + BN * (DUAL ? 2 : 1);  // staged rows per slice
-    constexpr int NCH = R / 32;                  // 16-byte chunks per thread per slice
-    constexpr int WN = BN / 32;                  // waves along N
+    constexpr int BM = 32 * WM, BNR = 64 * WN;   // activation rows / weight rows per tile
+    constexpr int R = BM + BNR;
+    constexpr int NCH = R / 8;                   // 16-byte pieces per lane per chunk
     constexpr int KSTEP_BYTES = 4 * Mma<T>::kLaneBytes;
-    constexpr int KSTEPS = kSliceBytes / KSTEP_BYTES;
-    static_assert((BM / 32) * WN == 4, "4 waves per workgroup");
+    constexpr int KSTEPS = kChunkBytes / KSTEP_BYTES;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
 
-    __shared__ __attribute__((aligned(16))) char smem[2 * R * kRowBytes];
+    __shared__ __attribute__((aligned(16))) char smem[R * kRowBytes];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = tid >> 6;
     const int wn = wid % WN, wm = wid / WN;
-    const int n0 = blockIdx.x * BN;
-    const int m0 = blockIdx.y * BM;
+    const int m0 = blockIdx.z * BM;
     const size_t kbytes = (size_t)p.K * sizeof(T);
+    const int nchunks = (int)(kbytes / kChunkBytes);
+    const int cps = (nchunks + (int)gridDim.y - 1) / (int)gridDim.y;   // chunks per split
+    const int c_begin = blockIdx.y * cps;
+    const int c_end = min(nchunks, c_begin + cps);
 
-    // per-thread source pointers of its chunks
     const char* src[NCH];
     int dst[NCH];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int q = tid + i * 256;
-        const int row = q >> 3, c = q & 7;
+        const int row = q >> 5, c = q & 31;
         const char* base;
         if (row < BM) {
             int m = m0 + row;
             m = m < p.M ? m : p.M - 1;
             base = reinterpret_cast<const char*>(p.A) + (size_t)m * p.lda * sizeof(T);
-        } else if (row < BM + BN) {
-            base = reinterpret_cast<const char*>(p.W) + (size_t)(n0 + row - BM) * kbytes;
         } else {
-            base = reinterpret_cast<const char*>(p.W2) + (size_t)(n0 + row - BM - BN) * kbytes;
+            const int r = row - BM;                 // weight row inside the tile
+            if constexpr (DUAL) {
+                // each wave's 64 weight rows = 32 gate rows followed by the 32 inner rows of the same columns
+                const int w = r >> 6, rr = r & 63;
+                const int col = blockIdx.x * (BNR / 2) + w * 32 + (rr & 31);
+                base = reinterpret_cast<const char*>(rr < 32 ? p.W : p.W2) + (size_t)col * kbytes;
+            } else {
+                base = reinterpret_cast<const char*>(p.W) + (size_t)(blockIdx.x * BNR + r) * kbytes;
+            }
         }
-        src[i] = base + c * 16;
+        src[i] = base + c * 16 + (size_t)c_begin * kChunkBytes;
         dst[i] = row * kRowBytes + c * 16;
     }
 
-    f32x4 acc[2][2], acc2[2][2];
+    f32x4 acc[4][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-            acc2[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int KT = (int)(kbytes / kSliceBytes);
     uint4 regs[NCH];
+    if (c_begin < c_end) {
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) regs[i] = *reinterpret_cast<const uint4*>(src[i]);
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) *reinterpret_cast<uint4*>(smem + dst[i]) = regs[i];
-    __syncthreads();
-
+        for (int i = 0; i < NCH; ++i) regs[i] = *reinterpret_cast<const uint4*>(src[i]);
+    }
     const int frow = lane & 15;
     const int fk = (lane >> 4) * Mma<T>::kLaneBytes;
-    for (int kt = 0; kt < KT; ++kt) {
-        const char* buf = smem + (kt & 1) * R * kRowBytes;
-        if (kt + 1 < KT) {
-            const size_t off = (size_t)(kt + 1) * kSliceBytes;
+    for (int ch = c_begin; ch < c_end; ++ch) {
+        if (ch != c_begin) __syncthreads();   // previous chunk fully consumed before it is overwritten
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) *reinterpret_cast<uint4*>(smem + dst[i]) = regs[i];
+        __syncthreads();
+        if (ch + 1 < c_end) {
+            const size_t off = (size_t)(ch + 1 - c_begin) * kChunkBytes;
 #pragma unroll
             for (int i = 0; i < NCH; ++i) regs[i] = *reinterpret_cast<const uint4*>(src[i] + off);
         }
-#pragma unroll
+#pragma unroll 2
         for (int ks = 0; ks < KSTEPS; ++ks) {
             const int kb = ks * KSTEP_BYTES + fk;
-            typename Mma<T>::Frag w[2], w2[2], x[2];
+            typename Mma<T>::Frag w[4], x[2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                w[t] = Mma<T>::ld(buf + (BM + wn * 32 + t * 16 + frow) * kRowBytes + kb);
-                if constexpr (DUAL) w2[t] = Mma<T>::ld(buf + (BM + BN + wn * 32 + t * 16 + frow) * kRowBytes + kb);
-                x[t] = Mma<T>::ld(buf + (wm * 32 + t * 16 + frow) * kRowBytes + kb);
-            }
+            for (int t = 0; t < 4; ++t) w[t] = Mma<T>::ld(smem + (BM + wn * 64 + t * 16 + frow) * kRowBytes + kb);
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
+            for (int t = 0; t < 2; ++t) x[t] = Mma<T>::ld(smem + (wm * 32 + t * 16 + frow) * kRowBytes + kb);
 #pragma unroll
-                for (int tm = 0; tm < 2; ++tm) {
-                    acc[tn][tm] = Mma<T>::mma(w[tn], x[tm], acc[tn][tm]);
-                    if constexpr (DUAL) acc2[tn][tm] = Mma<T>::mma(w2[tn], x[tm], acc2[tn][tm]);
-                }
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm) acc[tn][tm] = Mma<T>::mma(w[tn], x[tm], acc[tn][tm]);
         }
-        if (kt + 1 < KT) {
-            char* nbuf = smem + ((kt + 1) & 1) * R * kRowBytes;
-#pragma unroll
-            for (int i = 0; i < NCH; ++i) *reinterpret_cast<uint4*>(nbuf + dst[i]) = regs[i];
-        }
-        __syncthreads();
     }
 
-    // ---- epilogue: lane holds columns n..n+3 of row m for each (tn, tm)
-    const T* bias = reinterpret_cast<const T*>(p.bias);
-    const T* bias2 = reinterpret_cast<const T*>(p.bias2);
+    // ---- epilogue: lane holds 4 consecutive columns of row m for each (tn, tm)
+    const int quad = 4 * (lane >> 4);
+    if constexpr (EPI == EPI_PARTIAL) {
+        float* slab = p.partial + (size_t)blockIdx.y * p.M * p.N;
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-        const int n = n0 + wn * 32 + tn * 16 + 4 * (lane >> 4);
-        float bv[4] = {0.f, 0.f, 0.f, 0.f}, bv2[4] = {0.f, 0.f, 0.f, 0.f}, gv[4] = {1.f, 1.f, 1.f, 1.f};
-        if (bias) {
+        for (int tn = 0; tn < 4; ++tn) {
+            const int n = blockIdx.x * BNR + wn * 64 + tn * 16 + quad;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) bv[r] = Elem<T>::load(bias + n + r);
-        }
-        if constexpr (DUAL) {
-            if (bias2) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) bv2[r] = Elem<T>::load(bias2 + n + r);
+            for (int tm = 0; tm < 2; ++tm) {
+                const int m = m0 + wm * 32 + tm * 16 + (lane & 15);
+                if (m < p.M)
+                    *reinterpret_cast<float4*>(slab + (size_t)m * p.N + n) =
+                        make_float4(acc[tn][tm][0], acc[tn][tm][1], acc[tn][tm][2], acc[tn][tm][3]);
             }
         }
-        if constexpr (EPI == LCMHIP_EPI_RESID) {
-            if (p.gate) {
-                const float4 g = *reinterpret_cast<const float4*>(p.gate + n);
-                gv[0] = g.x; gv[1] = g.y; gv[2] = g.z; gv[3] = g.w;
+        return;
+    } else {
+        const T* bias = reinterpret_cast<const T*>(p.bias);
+        const T* bias2 = reinterpret_cast<const T*>(p.bias2);
+        constexpr int TN = DUAL ? 2 : 4;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = DUAL ? blockIdx.x * (BNR / 2) + wn * 32 + tn * 16 + quad
+                               : blockIdx.x * BNR + wn * 64 + tn * 16 + quad;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f}, bv2[4] = {0.f, 0.f, 0.f, 0.f}, gv[4] = {1.f, 1.f, 1.f, 1.f};
+            if (bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bv[r] = Elem<T>::load(bias + n + r);
             }
-        }
+            if constexpr (DUAL) {
+                if (bias2) {
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
-            const int m = m0 + wm * 32 + tm * 16 + (lane & 15);
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[tn][tm][r] + bv[r];
+                    for (int r = 0; r < 4; ++r) bv2[r] = Elem<T>::load(bias2 + n + r);
+                }
+            }
             if constexpr (EPI == LCMHIP_EPI_RESID) {
-                // rows [M, M + extra_rows) take a constant instead of the product
-                const bool real = m < p.M;
-                const bool extra = !real && m < p.M + p.extra_rows;
-                if (extra) {
-                    const float4 c = *reinterpret_cast<const float4*>(p.extra_const + n);
-                    v[0] = c.x; v[1] = c.y; v[2] = c.z; v[3] = c.w;
+                if (p.gate) {
+                    const float4 g = *reinterpret_cast<const float4*>(p.gate + n);
+                    gv[0] = g.x; gv[1] = g.y; gv[2] = g.z; gv[3] = g.w;
                 }
-                if (real || extra) {
-                    float4* dstp = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n);
-                    float4 o = *dstp;
-                    o.x += gv[0] * v[0]; o.y += gv[1] * v[1]; o.z += gv[2] * v[2]; o.w += gv[3] * v[3];
-                    *dstp = o;
-                }
-            } else {
-                if (m >= p.M) continue;
-                if constexpr (EPI == LCMHIP_EPI_RELU) {
+            }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                }
-                if constexpr (DUAL) {
+            for (int tm = 0; tm < 2; ++tm) {
+                const int m = m0 + wm * 32 + tm * 16 + (lane & 15);
+                float v[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float g = v[r];
-                        const float in = acc2[tn][tm][r] + bv2[r];
-                        v[r] = in * (g / (1.f + __expf(-g)));
+                for (int r = 0; r < 4; ++r) v[r] = acc[tn][tm][r] + bv[r];
+                if constexpr (EPI == LCMHIP_EPI_RESID) {
+                    // rows [M, M + extra_rows) take a constant instead of the product
+                    const bool real = m < p.M;
+                    const bool extra = !real && m < p.M + p.extra_rows;
+                    if (extra) {
+                        const float4 c = *reinterpret_cast<const float4*>(p.extra_const + n);
+                        v[0] = c.x; v[1] = c.y; v[2] = c.z; v[3] = c.w;
                     }
-                }
-                const size_t orow = p.out_rows ? (size_t)p.out_rows[m] : (size_t)m;
-                if constexpr (EPI == LCMHIP_EPI_STORE_F32) {
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + orow * p.ldo + n) =
-                        make_float4(v[0], v[1], v[2], v[3]);
-                } else if constexpr (sizeof(T) == 4) {
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + orow * p.ldo + n) =
-                        make_float4(v[0], v[1], v[2], v[3]);
+                    if (real || extra) {
+                        float4* dstp = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n);
+                        float4 o = *dstp;
+                        o.x += gv[0] * v[0]; o.y += gv[1] * v[1]; o.z += gv[2] * v[2]; o.w += gv[3] * v[3];
+                        *dstp = o;
+                    }
                 } else {
-                    uint2 o;
-                    o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                    o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + orow * p.ldo + n) = o;
+                    if (m >= p.M) continue;
+                    if constexpr (EPI == LCMHIP_EPI_RELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    }
+                    if constexpr (DUAL) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float g = v[r];
+                            const float in = acc[tn + 2][tm][r] + bv2[r];
+                            v[r] = in * (g / (1.f + __expf(-g)));
+                        }
+                    }
+                    const size_t orow = p.out_rows ? (size_t)p.out_rows[m] : (size_t)m;
+                    if constexpr (EPI == LCMHIP_EPI_STORE_F32 || sizeof(T) == 4) {
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + orow * p.ldo + n) =
+                            make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        uint2 o;
+                        o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                        o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + orow * p.ldo + n) = o;
+                    }
                 }
             }
         }
     }
 }
 
-template <typename T, int BM, int BN>
-static int dispatch_epi(const GemmArgs& a, hipStream_t st) {
-    const int rows = a.M + (a.epilogue == LCMHIP_EPI_RESID ? a.extra_rows : 0);
-    dim3 grid(a.N / BN, (rows + BM - 1) / BM), block(256);
-    switch (a.epilogue) {
-        case LCMHIP_EPI_STORE: hipLaunchKernelGGL((k_gemm<T, BM, BN, LCMHIP_EPI_STORE>), grid, block, 0, st, a); break;
-        case LCMHIP_EPI_STORE_F32: hipLaunchKernelGGL((k_gemm<T, BM, BN, LCMHIP_EPI_STORE_F32>), grid, block, 0, st, a); break;
-        case LCMHIP_EPI_RELU: hipLaunchKernelGGL((k_gemm<T, BM, BN, LCMHIP_EPI_RELU>), grid, block, 0, st, a); break;
-        case LCMHIP_EPI_SWIGLU: hipLaunchKernelGGL((k_gemm<T, BM, BN, LCMHIP_EPI_SWIGLU>), grid, block, 0, st, a); break;
-        case LCMHIP_EPI_RESID: hipLaunchKernelGGL((k_gemm<T, BM, BN, LCMHIP_EPI_RESID>), grid, block, 0, st, a); break;
+// Sums the split-K slabs and applies a (non-dual) epilogue.  One lane = 4 consecutive columns.
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void k_splitk_finish(GemmArgs p, int splits) {
+    const int n4 = p.N / 4;
+    const int rows = p.M + (EPI == LCMHIP_EPI_RESID ? p.extra_rows : 0);
+    const int64_t total = (int64_t)rows * n4;
+    const T* bias = reinterpret_cast<const T*>(p.bias);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / n4), n = (int)(i % n4) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (m < p.M) {
+            for (int s = 0; s < splits; ++s) {
+                const float4 t = *reinterpret_cast<const float4*>(p.partial + ((size_t)s * p.M + m) * p.N + n);
+                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+            }
+            if (bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += Elem<T>::load(bias + n + r);
+            }
+        } else {
+            const float4 c = *reinterpret_cast<const float4*>(p.extra_const + n);
+            v[0] = c.x; v[1] = c.y; v[2] = c.z; v[3] = c.w;
+        }
+        if constexpr (EPI == LCMHIP_EPI_RESID) {
+            float4 g = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (p.gate) g = *reinterpret_cast<const float4*>(p.gate + n);
+            float4* dstp = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n);
+            float4 o = *dstp;
+            o.x += g.x * v[0]; o.y += g.y * v[1]; o.z += g.z * v[2]; o.w += g.w * v[3];
+            *dstp = o;
+        } else {
+            if constexpr (EPI == LCMHIP_EPI_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            const size_t orow = p.out_rows ? (size_t)p.out_rows[m] : (size_t)m;
+            if constexpr (EPI == LCMHIP_EPI_STORE_F32 || sizeof(T) == 4) {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + orow * p.ldo + n) =
+                    make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                uint2 o;
+                o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + orow * p.ldo + n) = o;
+            }
+        }
+    }
+}
+
+// ---- host-side dispatch -------------------------------------------------------------------------------
+struct Plan {
+    int wm, wn;        // wave grid
+    int n_tiles, m_tiles, splits;
+};
+
+static Plan make_plan(const GemmArgs& a, bool may_split) {
+    const int rows = a.M;   // rows that go through the matrix cores
+    const bool dual = a.epilogue == LCMHIP_EPI_SWIGLU;
+    const int wrows = dual ? 2 * a.N : a.N;   // weight rows streamed
+    Plan pl{};
+    if (rows <= 32 && wrows % 256 == 0) { pl.wm = 1; pl.wn = 4; }
+    else if (rows <= 64 && wrows % 128 == 0) { pl.wm = 2; pl.wn = 2; }
+    else { pl.wm = 4; pl.wn = 1; }
+    const int bm = 32 * pl.wm, bnr = 64 * pl.wn;
+    pl.n_tiles = wrows / bnr;
+    pl.m_tiles = (rows + bm - 1) / bm;
+    pl.splits = 1;
+    if (may_split) {
+        const int nchunks = (int)((size_t)a.K * dtype_size(a.dtype) / kChunkBytes);
+        const int tiles = pl.n_tiles * pl.m_tiles;
+        // aim at ~2 workgroups' worth of loads per CU across the 256 CUs, at least 2 chunks per split
+        // only when there are enough chunks to share
+        int s = (384 + tiles - 1) / tiles;
+        s = std::min(s, nchunks);
+        s = std::min(s, a.max_splits > 0 ? a.max_splits : 64);
+        pl.splits = std::max(1, s);
+        // re-balance: every split gets the same number of chunks where possible
+        const int cps = (nchunks + pl.splits - 1) / pl.splits;
+        pl.splits = (nchunks + cps - 1) / cps;
+    }
+    return pl;
+}
+
+template <typename T, int WM, int WN>
+static int launch_cfg(const GemmArgs& a, const Plan& pl, int epi, hipStream_t st) {
+    dim3 grid(pl.n_tiles, pl.splits, pl.m_tiles), block(256);
+    switch (epi) {
+        case LCMHIP_EPI_STORE: hipLaunchKernelGGL((k_gemm<T, WM, WN, LCMHIP_EPI_STORE>), grid, block, 0, st, a); break;
+        case LCMHIP_EPI_STORE_F32: hipLaunchKernelGGL((k_gemm<T, WM, WN, LCMHIP_EPI_STORE_F32>), grid, block, 0, st, a); break;
+        case LCMHIP_EPI_RELU: hipLaunchKernelGGL((k_gemm<T, WM, WN, LCMHIP_EPI_RELU>), grid, block, 0, st, a); break;
+        case LCMHIP_EPI_SWIGLU: hipLaunchKernelGGL((k_gemm<T, WM, WN, LCMHIP_EPI_SWIGLU>), grid, block, 0, st, a); break;
+        case LCMHIP_EPI_RESID: hipLaunchKernelGGL((k_gemm<T, WM, WN, LCMHIP_EPI_RESID>), grid, block, 0, st, a); break;
+        case EPI_PARTIAL: hipLaunchKernelGGL((k_gemm<T, WM, WN, EPI_PARTIAL>), grid, block, 0, st, a); break;
         default: return fail(LCMHIP_ERR_INVALID, "gemm: unknown epilogue");
     }
     LCM_HIP_CHECK(hipGetLastError());
     return LCMHIP_OK;
 }
 
-// Tile choice by row count: few rows -> narrow-M tiles keep the grid large; otherwise 128 x 32
-// (all rows of a sentence step share one pass over the weight tile).
-static void pick_tile(const GemmArgs& a, int& bm, int& bn) {
-    const int rows = a.M + (a.epilogue == LCMHIP_EPI_RESID ? a.extra_rows : 0);
-    const bool dual = a.epilogue == LCMHIP_EPI_SWIGLU;  // two weight tiles: keep LDS under 64 KiB
-    if (rows <= 32 && !dual && a.N % 128 == 0) { bm = 32; bn = 128; }
-    else if (rows <= 64 && a.N % 64 == 0) { bm = 64; bn = 64; }
-    else { bm = 128; bn = 32; }
+template <typename T>
+static int launch_plan(const GemmArgs& a, const Plan& pl, int epi, hipStream_t st) {
+    if (pl.wm == 1) return launch_cfg<T, 1, 4>(a, pl, epi, st);
+    if (pl.wm == 2) return launch_cfg<T, 2, 2>(a, pl, epi, st);
+    return launch_cfg<T, 4, 1>(a, pl, epi, st);
 }
 
 template <typename T>
-static int dispatch_tile(const GemmArgs& a, hipStream_t st) {
-    int bm, bn;
-    pick_tile(a, bm, bn);
-    if (bm == 32) return dispatch_epi<T, 32, 128>(a, st);
-    if (bm == 64) return dispatch_epi<T, 64, 64>(a, st);
-    return dispatch_epi<T, 128, 32>(a, st);
+static int launch_finish(const GemmArgs& a, int splits, hipStream_t st) {
+    const int rows = a.M + (a.epilogue == LCMHIP_EPI_RESID ? a.extra_rows : 0);
+    const int64_t total = (int64_t)rows * (a.N / 4);
+    const int grid = (int)std::min<int64_t>(2048, (total + 255) / 256);
+    switch (a.epilogue) {
+        case LCMHIP_EPI_STORE: hipLaunchKernelGGL((k_splitk_finish<T, LCMHIP_EPI_STORE>), dim3(grid), dim3(256), 0, st, a, splits); break;
+        case LCMHIP_EPI_STORE_F32: hipLaunchKernelGGL((k_splitk_finish<T, LCMHIP_EPI_STORE_F32>), dim3(grid), dim3(256), 0, st, a, splits); break;
+        case LCMHIP_EPI_RELU: hipLaunchKernelGGL((k_splitk_finish<T, LCMHIP_EPI_RELU>), dim3(grid), dim3(256), 0, st, a, splits); break;
+        case LCMHIP_EPI_RESID: hipLaunchKernelGGL((k_splitk_finish<T, LCMHIP_EPI_RESID>), dim3(grid), dim3(256), 0, st, a, splits); break;
+        default: return fail(LCMHIP_ERR_INVALID, "gemm: epilogue cannot be applied after split-K");
+    }
+    LCM_HIP_CHECK(hipGetLastError());
+    return LCMHIP_OK;
+}
+
+static int check_args(const GemmArgs& a) {
+    LCM_REQUIRE(a.M >= 1 && a.N >= 1 && a.K >= 1, "gemm: empty problem");
+    const size_t es = dtype_size(a.dtype);
+    LCM_REQUIRE(a.dtype == LCMHIP_BF16 || a.dtype == LCMHIP_F32, "gemm: unknown dtype");
+    LCM_REQUIRE((a.K * es) % kChunkBytes == 0, "gemm: K must cover whole 512-byte chunks (256 bf16 / 128 f32 elements)");
+    LCM_REQUIRE(a.N % 64 == 0, "gemm: N must be a multiple of 64");
+    LCM_REQUIRE(a.epilogue != LCMHIP_EPI_SWIGLU || (a.W2 != nullptr && a.N % 32 == 0), "gemm: SWIGLU needs W2");
+    LCM_REQUIRE(((size_t)a.lda * es) % 16 == 0 && ((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.W % 16) == 0,
+                "gemm: operands must be 16-byte aligned");
+    LCM_REQUIRE(a.extra_rows == 0 || (a.epilogue == LCMHIP_EPI_RESID && a.extra_const), "gemm: extra rows need RESID");
+    return LCMHIP_OK;
+}
+
+int gemm_partial_splits(const GemmArgs& a) {
+    if (check_args(a) != LCMHIP_OK) return -1;
+    return make_plan(a, true).splits;
+}
+
+// Writes raw fp32 partial tiles to a.partial ([splits][M][N]); returns the split count through *splits.
+int launch_gemm_partial(const GemmArgs& a, int* splits, hipStream_t st) {
+    LCM_TRY(check_args(a));
+    LCM_REQUIRE(a.partial != nullptr && a.epilogue != LCMHIP_EPI_SWIGLU, "gemm: partial mode needs a slab and a linear epilogue");
+    const Plan pl = make_plan(a, true);
+    LCM_REQUIRE((size_t)pl.splits * a.M * a.N * 4 <= a.partial_bytes, "gemm: split-K slab too small");
+    *splits = pl.splits;
+    return a.dtype == LCMHIP_BF16 ? launch_plan<bf16_t>(a, pl, EPI_PARTIAL, st) : launch_plan<float>(a, pl, EPI_PARTIAL, st);
 }
 
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
-    LCM_REQUIRE(a.M >= 1 && a.N >= 1 && a.K >= 1, "gemm: empty problem");
-    const size_t es = dtype_size(a.dtype);
-    LCM_REQUIRE((a.K * es) % kSliceBytes == 0, "gemm: K must cover whole 128-byte slices");
-    LCM_REQUIRE(a.N % 32 == 0, "gemm: N must be a multiple of 32");
-    LCM_REQUIRE(((size_t)a.lda * es) % 16 == 0 && ((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.W % 16) == 0,
-                "gemm: operands must be 16-byte aligned");
-    LCM_REQUIRE(a.epilogue != LCMHIP_EPI_SWIGLU || a.W2 != nullptr, "gemm: SWIGLU needs W2");
-    LCM_REQUIRE(a.ldo % 4 == 0 && ((uintptr_t)a.out % 16) == 0, "gemm: output must be 16-byte aligned");
-    LCM_REQUIRE(a.extra_rows == 0 || (a.epilogue == LCMHIP_EPI_RESID && a.extra_const), "gemm: extra rows need RESID");
-    if (a.dtype == LCMHIP_BF16) return dispatch_tile<bf16_t>(a, st);
-    if (a.dtype == LCMHIP_F32) return dispatch_tile<float>(a, st);
-    return fail(LCMHIP_ERR_INVALID, "gemm: unknown dtype");
+    LCM_TRY(check_args(a));
+    LCM_REQUIRE(a.out != nullptr && a.ldo % 4 == 0 && ((uintptr_t)a.out % 16) == 0, "gemm: output must be 16-byte aligned");
+    const bool can_split = a.partial != nullptr && a.epilogue != LCMHIP_EPI_SWIGLU;
+    Plan pl = make_plan(a, can_split);
+    if (can_split && (size_t)pl.splits * a.M * a.N * 4 > a.partial_bytes) pl.splits = 1;
+    if (pl.splits > 1) {
+        LCM_TRY(a.dtype == LCMHIP_BF16 ? launch_plan<bf16_t>(a, pl, EPI_PARTIAL, st) : launch_plan<float>(a, pl, EPI_PARTIAL, st));
+        return a.dtype == LCMHIP_BF16 ? launch_finish<bf16_t>(a, pl.splits, st) : launch_finish<float>(a, pl.splits, st);
+    }
+    if (a.epilogue == LCMHIP_EPI_RESID && a.extra_rows > 0) {
+        // direct RESID with extra constant rows: the row tiles must cover them
+        Plan p2 = pl;
+        const int bm = 32 * p2.wm;
+        p2.m_tiles = (a.M + a.extra_rows + bm - 1) / bm;
+        return a.dtype == LCMHIP_BF16 ? launch_plan<bf16_t>(a, p2, a.epilogue, st) : launch_plan<float>(a, p2, a.epilogue, st);
+    }
+    return a.dtype == LCMHIP_BF16 ? launch_plan<bf16_t>(a, pl, a.epilogue, st) : launch_plan<float>(a, pl, a.epilogue, st);
 }
 
 }  // namespace lcmhip

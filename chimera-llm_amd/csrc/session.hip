@@ -192,6 +192,8 @@ struct lcmhip_session {
     char *act_a = nullptr, *act_q = nullptr, *act_k = nullptr, *act_v = nullptr, *act_o = nullptr, *act_h = nullptr,
          *act_in = nullptr;
     float* kept_ctx = nullptr;
+    float *slab_p = nullptr, *slab_q = nullptr;   // split-K slabs: pending products / internal finishing
+    size_t slab_bytes = 0;
     // host state
     std::vector<int32_t> h_slot;
     int n_active = 0, ctx_len = 0;
@@ -206,6 +208,8 @@ struct lcmhip_session {
 };
 
 namespace lcmhip {
+
+constexpr int kMaxSplits = 12;
 
 struct Carver {
     char* base;
@@ -259,6 +263,9 @@ static size_t carve(lcmhip_session* s, char* base) {
     s->act_o = c.take<char>(R * dm * es);
     s->act_h = c.take<char>(R * F * es);
     s->kept_ctx = s->keep_context ? c.take<float>(B * cap * dm * 4) : nullptr;
+    s->slab_bytes = (size_t)kMaxSplits * R * std::max(dm, D) * 4;
+    s->slab_p = c.take<float>(s->slab_bytes);
+    s->slab_q = c.take<float>(s->slab_bytes);
     return c.off;
 }
 
@@ -316,45 +323,81 @@ __global__ __launch_bounds__(256) void k_keep_rows(const T* __restrict__ src, fl
     }
 }
 
-// ---- GEMM helper with profiling ---------------------------------------------------------------------
-static int gemm(lcmhip_session* s, const char* tag, const void* A, int lda, const Lin& W, const Lin* W2,
-                const float* gate, void* out, int ldo, int M, int epi, hipStream_t st,
-                const int32_t* out_rows = nullptr, int extra_rows = 0, const float* extra_const = nullptr) {
+// ---- GEMM helpers with profiling ---------------------------------------------------------------------
+static GemmArgs gemm_args(lcmhip_session* s, const void* A, int lda, const Lin& W, const Lin* W2, int M, int epi) {
     GemmArgs a{};
     a.A = A; a.lda = lda;
     a.W = W.w; a.bias = W.b;
     a.W2 = W2 ? W2->w : nullptr; a.bias2 = W2 ? W2->b : nullptr;
-    a.gate = gate;
-    a.out = out; a.ldo = ldo; a.out_rows = out_rows;
     a.M = M; a.N = W.out; a.K = W.in;
     a.epilogue = epi; a.dtype = s->model->desc.dtype;
-    a.extra_rows = extra_rows; a.extra_const = extra_const;
+    a.max_splits = kMaxSplits;
+    return a;
+}
+
+static void gemm_cost(const GemmArgs& a, double out_es, double* bytes, double* flops) {
     const double es = (double)dtype_size(a.dtype);
-    const double nw = W2 ? 2.0 : 1.0;
-    const double out_es = (epi == LCMHIP_EPI_STORE_F32) ? 4.0 : (epi == LCMHIP_EPI_RESID ? 8.0 : es);
-    const double bytes = nw * a.N * (double)a.K * es + (double)M * a.K * es + (double)(M + extra_rows) * a.N * out_es;
-    const double flops = 2.0 * nw * M * (double)a.N * a.K;
+    const double nw = a.W2 ? 2.0 : 1.0;
+    *bytes = nw * a.N * (double)a.K * es + (double)a.M * a.K * es + (double)(a.M + a.extra_rows) * a.N * out_es;
+    *flops = 2.0 * nw * a.M * (double)a.N * a.K;
+}
+
+// Product with its epilogue applied (split-K through slab_q + a finishing pass when that pays).
+static int gemm(lcmhip_session* s, const char* tag, const void* A, int lda, const Lin& W, const Lin* W2,
+                const float* gate, void* out, int ldo, int M, int epi, hipStream_t st,
+                const int32_t* out_rows = nullptr, int extra_rows = 0, const float* extra_const = nullptr) {
+    GemmArgs a = gemm_args(s, A, lda, W, W2, M, epi);
+    a.gate = gate;
+    a.out = out; a.ldo = ldo; a.out_rows = out_rows;
+    a.extra_rows = extra_rows; a.extra_const = extra_const;
+    a.partial = s->slab_q; a.partial_bytes = s->slab_bytes;
+    double bytes, flops;
+    const double es = (double)dtype_size(a.dtype);
+    gemm_cost(a, epi == LCMHIP_EPI_STORE_F32 ? 4.0 : (epi == LCMHIP_EPI_RESID ? 8.0 : es), &bytes, &flops);
     ProfScope ps(&s->prof, tag, bytes, flops, st);
     return launch_gemm(a, st);
 }
 
-static int norm(lcmhip_session* s, const char* tag, const float* x, const NormW& w, const float* shift,
-                const float* scale, void* y, int rows, int kind, hipStream_t st) {
-    const lcmhip_model_desc& d = s->model->desc;
-    const double es = (double)dtype_size(d.dtype);
-    ProfScope ps(&s->prof, tag, rows * (double)d.model_dim * (4.0 + es), 0.0, st);
-    return launch_norm_modulate(x, w.w, w.b, shift, scale, y, rows, d.model_dim, kind, d.norm_eps, d.dtype, st);
+// Product left in slab_p for the next norm kernel to fold into the residual stream.
+static int gemm_pending(lcmhip_session* s, const char* tag, const void* A, int lda, const Lin& W, const float* gate,
+                        int M, Pending* pend, hipStream_t st) {
+    GemmArgs a = gemm_args(s, A, lda, W, nullptr, M, LCMHIP_EPI_STORE_F32);
+    a.bias = nullptr;
+    a.partial = s->slab_p; a.partial_bytes = s->slab_bytes;
+    double bytes, flops;
+    gemm_cost(a, 0.0, &bytes, &flops);
+    int splits = 0;
+    {
+        ProfScope ps(&s->prof, tag, bytes, flops, st);
+        LCM_TRY(launch_gemm_partial(a, &splits, st));
+    }
+    *pend = Pending{};
+    pend->partial = s->slab_p;
+    pend->splits = splits;
+    pend->M = M;
+    pend->bias = W.b;
+    pend->gate = gate;
+    return LCMHIP_OK;
 }
 
-static int ffn(lcmhip_session* s, const char* tag_in, const char* tag_out, const lcmhip_tower_desc& t, const FfnW& f,
-               const void* a, const float* gate, float* xres, int rows, int extra_unused, hipStream_t st) {
-    (void)extra_unused;
+static int norm(lcmhip_session* s, const char* tag, float* x, const NormW& w, const float* shift,
+                const float* scale, void* y, int rows_total, int rows_norm, int kind, const Pending* pend,
+                hipStream_t st) {
+    const lcmhip_model_desc& d = s->model->desc;
+    const double es = (double)dtype_size(d.dtype);
+    double bytes = rows_norm * (double)d.model_dim * (4.0 + es);
+    if (pend) bytes += (double)rows_total * d.model_dim * 4.0 * (1.0 + pend->splits);
+    ProfScope ps(&s->prof, tag, bytes, 0.0, st);
+    return launch_norm_modulate(x, w.w, w.b, shift, scale, y, rows_total, rows_norm, d.model_dim, kind, d.norm_eps,
+                                d.dtype, pend, st);
+}
+
+static int ffn_in(lcmhip_session* s, const char* tag, const lcmhip_tower_desc& t, const FfnW& f, const void* a, int rows,
+                  hipStream_t st) {
     const int d = s->model->desc.model_dim;
     if (t.ffn_kind == LCMHIP_FFN_SWIGLU)
-        LCM_TRY(gemm(s, tag_in, a, d, f.gate, &f.inner, nullptr, s->act_h, t.ffn_dim, rows, LCMHIP_EPI_SWIGLU, st));
-    else
-        LCM_TRY(gemm(s, tag_in, a, d, f.inner, nullptr, nullptr, s->act_h, t.ffn_dim, rows, LCMHIP_EPI_RELU, st));
-    return gemm(s, tag_out, s->act_h, t.ffn_dim, f.out, nullptr, gate, xres, d, rows, LCMHIP_EPI_RESID, st);
+        return gemm(s, tag, a, d, f.gate, &f.inner, nullptr, s->act_h, t.ffn_dim, rows, LCMHIP_EPI_SWIGLU, st);
+    return gemm(s, tag, a, d, f.inner, nullptr, nullptr, s->act_h, t.ffn_dim, rows, LCMHIP_EPI_RELU, st);
 }
 
 }  // namespace lcmhip
@@ -659,7 +702,7 @@ int lcmhip_context_append(lcmhip_session* s, const float* x, int32_t n_tokens, i
         if (tc.pos_kind == LCMHIP_POS_LEARNED) LCM_TRY(launch_add_pos(s->xres, m->pos_table, s->pos_rows, R, dm, d.dtype, st));
         for (int l = 0; l < tc.num_layers; ++l) {
             const CtxLayer& L = m->ctx[l];
-            LCM_TRY(norm(s, "ctx.norm", s->xres, L.sa_norm, nullptr, nullptr, s->act_a, R, tc.norm_kind, st));
+            LCM_TRY(norm(s, "ctx.norm", s->xres, L.sa_norm, nullptr, nullptr, s->act_a, R, R, tc.norm_kind, nullptr, st));
             LCM_TRY(gemm(s, "ctx.qkv", s->act_a, dm, L.sa.q, nullptr, nullptr, s->act_q, dm, R, LCMHIP_EPI_STORE, st));
             LCM_TRY(gemm(s, "ctx.qkv", s->act_a, dm, L.sa.k, nullptr, nullptr, s->act_k, dm, R, LCMHIP_EPI_STORE, st));
             LCM_TRY(gemm(s, "ctx.qkv", s->act_a, dm, L.sa.v, nullptr, nullptr, s->act_v, dm, R, LCMHIP_EPI_STORE, st));
@@ -675,10 +718,11 @@ int lcmhip_context_append(lcmhip_session* s, const float* x, int32_t n_tokens, i
                                          n, sc, tc.num_heads, s->cap, pos0, 1, d.dtype, st));
             }
             LCM_TRY(gemm(s, "ctx.attn_out", s->act_o, dm, L.sa.o, nullptr, nullptr, s->xres, dm, R, LCMHIP_EPI_RESID, st));
-            LCM_TRY(norm(s, "ctx.norm", s->xres, L.ffn_norm, nullptr, nullptr, s->act_a, R, tc.norm_kind, st));
-            LCM_TRY(ffn(s, "ctx.ffn_in", "ctx.ffn_out", tc, L.ffn, s->act_a, nullptr, s->xres, R, 0, st));
+            LCM_TRY(norm(s, "ctx.norm", s->xres, L.ffn_norm, nullptr, nullptr, s->act_a, R, R, tc.norm_kind, nullptr, st));
+            LCM_TRY(ffn_in(s, "ctx.ffn_in", tc, L.ffn, s->act_a, R, st));
+            LCM_TRY(gemm(s, "ctx.ffn_out", s->act_h, tc.ffn_dim, L.ffn.out, nullptr, nullptr, s->xres, dm, R, LCMHIP_EPI_RESID, st));
         }
-        LCM_TRY(norm(s, "ctx.norm", s->xres, m->ctx_final, nullptr, nullptr, s->act_a, R, tc.norm_kind, st));
+        LCM_TRY(norm(s, "ctx.norm", s->xres, m->ctx_final, nullptr, nullptr, s->act_a, R, R, tc.norm_kind, nullptr, st));
         // cross-attention keys / values of the new context positions, every denoiser layer
         for (int l = 0; l < d.denoiser.num_layers; ++l) {
             LCM_TRY(gemm(s, "ctx.cross_kv", s->act_a, dm, m->den[l].ca.k, nullptr, nullptr, s->cross_k + l * cross_layer, dm, R,
@@ -729,20 +773,23 @@ int lcmhip_denoise(lcmhip_session* s, const float* noise, float* out, float* lat
         const DdimScalars& sc = s->scalars[si];
         const int rows = sc.mode == 1 ? 2 * B : B;
         const float* mod_step = s->mod_table + (size_t)si * L * 9 * dm;
-        // initial projection: both halves of the doubled batch see the same latents
+        // initial projection: both halves of the doubled batch see the same latents; the product stays
+        // in the split-K slab and the first norm kernel writes it (duplicated) into the residual stream
         LCM_TRY(launch_cast(lat, s->act_in, (int64_t)B * D, d.dtype, st));
-        LCM_TRY(gemm(s, "den.initial_proj", s->act_in, D, m->init_proj, nullptr, nullptr, s->xres, dm, B, LCMHIP_EPI_STORE_F32, st));
-        if (rows == 2 * B) LCM_HIP_CHECK(hipMemcpyAsync(s->xres + (size_t)B * dm, s->xres, (size_t)B * dm * 4, hipMemcpyDeviceToDevice, st));
+        Pending pend;
+        LCM_TRY(gemm_pending(s, "den.initial_proj", s->act_in, D, m->init_proj, nullptr, B, &pend, st));
+        pend.init = 1;
+        pend.dup = 1;
         for (int l = 0; l < L; ++l) {
             const DenLayer& Ly = m->den[l];
             const float* mod = mod_step + (size_t)l * 9 * dm;
             // self-attention over a single position: softmax == 1, so the block is output_proj(v_proj(h))
-            LCM_TRY(norm(s, "den.norm_mod", s->xres, Ly.sa_norm, mod, mod + dm, s->act_a, rows, td.norm_kind, st));
+            LCM_TRY(norm(s, "den.norm_mod", s->xres, Ly.sa_norm, mod, mod + dm, s->act_a, rows, rows, td.norm_kind, &pend, st));
             LCM_TRY(gemm(s, "den.self_v", s->act_a, dm, Ly.sa.v, nullptr, nullptr, s->act_v, dm, rows, LCMHIP_EPI_STORE, st));
-            LCM_TRY(gemm(s, "den.self_o", s->act_v, dm, Ly.sa.o, nullptr, mod + 2 * dm, s->xres, dm, rows, LCMHIP_EPI_RESID, st));
+            LCM_TRY(gemm_pending(s, "den.self_o", s->act_v, dm, Ly.sa.o, mod + 2 * dm, rows, &pend, st));
             // cross-attention: conditional rows attend to [zero slot, context]; unconditional rows only
             // see the zero slot, whose value is a per-layer constant
-            LCM_TRY(norm(s, "den.norm_mod", s->xres, Ly.ca_norm, mod + 3 * dm, mod + 4 * dm, s->act_a, B, td.norm_kind, st));
+            LCM_TRY(norm(s, "den.norm_mod", s->xres, Ly.ca_norm, mod + 3 * dm, mod + 4 * dm, s->act_a, rows, B, td.norm_kind, &pend, st));
             LCM_TRY(gemm(s, "den.cross_q", s->act_a, dm, Ly.ca.q, nullptr, nullptr, s->act_q, dm, B, LCMHIP_EPI_STORE, st));
             {
                 ProfScope ps(&s->prof, "den.cross_attn", 2.0 * B * (double)nkeys * dm * es + 2.0 * B * dm * es,
@@ -750,12 +797,13 @@ int lcmhip_denoise(lcmhip_session* s, const float* noise, float* out, float* lat
                 LCM_TRY(launch_attention(s->act_q, s->cross_k + l * cross_layer, s->cross_v + l * cross_layer, s->slot_map,
                                          s->act_o, B, 1, td.num_heads, s->cap + 1, nkeys, 0, d.dtype, st));
             }
-            LCM_TRY(gemm(s, "den.cross_o", s->act_o, dm, Ly.ca.o, nullptr, mod + 5 * dm, s->xres, dm, B, LCMHIP_EPI_RESID, st,
-                         nullptr, rows - B, s->uconst + (size_t)l * dm));
-            LCM_TRY(norm(s, "den.norm_mod", s->xres, Ly.ffn_norm, mod + 6 * dm, mod + 7 * dm, s->act_a, rows, td.norm_kind, st));
-            LCM_TRY(ffn(s, "den.ffn_in", "den.ffn_out", td, Ly.ffn, s->act_a, mod + 8 * dm, s->xres, rows, 0, st));
+            LCM_TRY(gemm_pending(s, "den.cross_o", s->act_o, dm, Ly.ca.o, mod + 5 * dm, B, &pend, st));
+            pend.extra_const = s->uconst + (size_t)l * dm;
+            LCM_TRY(norm(s, "den.norm_mod", s->xres, Ly.ffn_norm, mod + 6 * dm, mod + 7 * dm, s->act_a, rows, rows, td.norm_kind, &pend, st));
+            LCM_TRY(ffn_in(s, "den.ffn_in", td, Ly.ffn, s->act_a, rows, st));
+            LCM_TRY(gemm_pending(s, "den.ffn_out", s->act_h, td.ffn_dim, Ly.ffn.out, mod + 8 * dm, rows, &pend, st));
         }
-        LCM_TRY(norm(s, "den.norm_mod", s->xres, m->den_final, nullptr, nullptr, s->act_a, rows, td.norm_kind, st));
+        LCM_TRY(norm(s, "den.norm_mod", s->xres, m->den_final, nullptr, nullptr, s->act_a, rows, rows, td.norm_kind, &pend, st));
         LCM_TRY(gemm(s, "den.final_proj", s->act_a, dm, m->final_proj, nullptr, nullptr, s->outp, D, rows, LCMHIP_EPI_STORE_F32, st));
         {
             ProfScope ps(&s->prof, "den.ddim_cfg_step", (double)B * D * 4.0 * (rows == 2 * B ? 5.0 : 4.0), 0.0, st);
@@ -812,17 +860,46 @@ int lcmhip_norm_modulate(const float* x, const void* weight, const void* bias, c
                          void* y, int32_t rows, int32_t dim, int32_t norm_kind, float eps, int32_t dtype, void* stream) {
     LCM_REQUIRE(x && y, "norm_modulate: null argument");
     LCM_REQUIRE(norm_kind == LCMHIP_NORM_RMS || norm_kind == LCMHIP_NORM_LAYERNORM, "norm_modulate: unknown norm kind");
-    return launch_norm_modulate(x, weight, bias, shift, scale, y, rows, dim, norm_kind, eps, dtype, static_cast<hipStream_t>(stream));
+    return launch_norm_modulate(const_cast<float*>(x), weight, bias, shift, scale, y, rows, rows, dim, norm_kind, eps, dtype,
+                                nullptr, static_cast<hipStream_t>(stream));
 }
 
 int lcmhip_gemm(const void* A, int32_t lda, const void* W, const void* W2, const void* bias, const void* bias2,
                 const float* gate, void* out, int32_t ldo, int32_t M, int32_t N, int32_t K, int32_t epilogue,
-                int32_t dtype, void* stream) {
+                int32_t dtype, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
     LCM_REQUIRE(A && W && out, "gemm: null argument");
     GemmArgs a{};
     a.A = A; a.lda = lda; a.W = W; a.W2 = W2; a.bias = bias; a.bias2 = bias2; a.gate = gate;
     a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.epilogue = epilogue; a.dtype = dtype;
+    a.partial = splitk_ws; a.partial_bytes = splitk_ws_bytes; a.max_splits = kMaxSplits;
     return launch_gemm(a, static_cast<hipStream_t>(stream));
+}
+
+int lcmhip_gemm_partial(const void* A, int32_t lda, const void* W, float* slab, size_t slab_bytes, int32_t* splits,
+                        int32_t M, int32_t N, int32_t K, int32_t dtype, void* stream) {
+    LCM_REQUIRE(A && W && slab && splits, "gemm_partial: null argument");
+    GemmArgs a{};
+    a.A = A; a.lda = lda; a.W = W; a.M = M; a.N = N; a.K = K; a.epilogue = LCMHIP_EPI_STORE_F32; a.dtype = dtype;
+    a.partial = slab; a.partial_bytes = slab_bytes;
+    a.max_splits = (int)std::min<size_t>(kMaxSplits, slab_bytes / ((size_t)M * N * 4));
+    LCM_REQUIRE(a.max_splits >= 1, "gemm_partial: slab too small for one split");
+    int sp = 0;
+    LCM_TRY(launch_gemm_partial(a, &sp, static_cast<hipStream_t>(stream)));
+    *splits = sp;
+    return LCMHIP_OK;
+}
+
+int lcmhip_residual_norm(float* x, const float* slab, int32_t splits, int32_t M, const void* bias, const float* gate,
+                         const float* extra_const, int32_t dup, int32_t init, const void* weight, const void* norm_bias,
+                         const float* shift, const float* scale, void* y, int32_t rows_total, int32_t rows_norm,
+                         int32_t dim, int32_t norm_kind, float eps, int32_t dtype, void* stream) {
+    LCM_REQUIRE(x && slab && y, "residual_norm: null argument");
+    LCM_REQUIRE(norm_kind == LCMHIP_NORM_RMS || norm_kind == LCMHIP_NORM_LAYERNORM, "residual_norm: unknown norm kind");
+    Pending pd;
+    pd.partial = slab; pd.splits = splits; pd.M = M; pd.bias = bias; pd.gate = gate; pd.extra_const = extra_const;
+    pd.dup = dup; pd.init = init;
+    return launch_norm_modulate(x, weight, norm_bias, shift, scale, y, rows_total, rows_norm, dim, norm_kind, eps, dtype, &pd,
+                                static_cast<hipStream_t>(stream));
 }
 
 int lcmhip_ddim_cfg_step(const float* sample, const float* out_cond, const float* out_uncond, float* prev_sample,

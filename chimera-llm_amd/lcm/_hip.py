@@ -27,7 +27,8 @@ EXPORTS = [
     "lcmhip_session_set_schedule", "lcmhip_session_reset", "lcmhip_context_append", "lcmhip_denoise",
     "lcmhip_session_reorder", "lcmhip_session_context_len", "lcmhip_session_num_active",
     "lcmhip_session_read_context", "lcmhip_session_profile_enable", "lcmhip_session_profile",
-    "lcmhip_normalize", "lcmhip_denormalize", "lcmhip_norm_modulate", "lcmhip_gemm",
+    "lcmhip_normalize", "lcmhip_denormalize", "lcmhip_norm_modulate", "lcmhip_gemm", "lcmhip_gemm_partial",
+    "lcmhip_residual_norm",
     "lcmhip_ddim_cfg_step", "lcmhip_attention",
 ]
 
@@ -87,7 +88,9 @@ def _load() -> C.CDLL:
         "lcmhip_normalize": [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp],
         "lcmhip_denormalize": [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp],
         "lcmhip_norm_modulate": [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp],
-        "lcmhip_gemm": [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+        "lcmhip_gemm": [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, C.c_size_t, vp],
+        "lcmhip_gemm_partial": [vp, i32, vp, vp, C.c_size_t, C.POINTER(i32), i32, i32, i32, i32, vp],
+        "lcmhip_residual_norm": [vp, vp, i32, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
         "lcmhip_ddim_cfg_step": [vp, vp, vp, vp, vp, i32, i32, f32, f32, C.POINTER(DenoiseParams), vp],
         "lcmhip_attention": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     }

@@ -211,10 +211,31 @@ int lcmhip_norm_modulate(const float* x, const void* weight, const void* bias, c
  * attention.py:151-185, factory.py:247-254, 277-300, projection.py:80-86, frontend.py:139.
  * A: (M, K) lda; W, W2: (N, K); bias, bias2: (N,) in `dtype` or NULL; gate: (N,) fp32 or NULL;
  * out: (M, N) ldo -- operand dtype for STORE/RELU/SWIGLU, fp32 for STORE_F32/RESID.
- * K must be a multiple of 128 bytes of operands, N a multiple of 32. */
+ * K must cover whole 512-byte chunks of operands (256 bf16 / 128 f32 elements), N a multiple of
+ * 64.  `splitk_ws` (fp32, `splitk_ws_bytes` long) is optional scratch: with it the K range may be
+ * split over workgroups (partial tiles summed by a finishing pass; deterministic). */
 int lcmhip_gemm(const void* A, int32_t lda, const void* W, const void* W2, const void* bias,
                 const void* bias2, const float* gate, void* out, int32_t ldo, int32_t M, int32_t N,
-                int32_t K, int32_t epilogue, int32_t dtype, void* stream);
+                int32_t K, int32_t epilogue, int32_t dtype, float* splitk_ws, size_t splitk_ws_bytes,
+                void* stream);
+
+/* The residual update + pre-norm of one denoiser sub-block, fed from a split-K slab
+ * (lcm_denoiser.py:445-473 / 496-521 / 527-546: `seqs = residual + gate * block(...)` followed
+ * by the next block's `layer_norm(seqs) * (1 + scale) + shift`).
+ * First  x[r] = (init ? 0 : x[r]) + gate * (sum_s slab[s][src(r)] + bias)  for rows r < M
+ * (src(r) = r) and, for rows M <= r < rows_total, either the same with src(r) = r - M (dup != 0)
+ * or x[r] += gate * extra_const (dup == 0); then rows [0, rows_norm) are normalised like
+ * lcmhip_norm_modulate into y.  slab: (splits, M, dim) fp32 -- the output of lcmhip_gemm_partial. */
+int lcmhip_residual_norm(float* x, const float* slab, int32_t splits, int32_t M, const void* bias,
+                         const float* gate, const float* extra_const, int32_t dup, int32_t init,
+                         const void* weight, const void* norm_bias, const float* shift,
+                         const float* scale, void* y, int32_t rows_total, int32_t rows_norm,
+                         int32_t dim, int32_t norm_kind, float eps, int32_t dtype, void* stream);
+
+/* Split-K partial products only: slab (splits, M, N) fp32 without bias; `*splits` is chosen by
+ * the library (<= slab_bytes / (M * N * 4)). */
+int lcmhip_gemm_partial(const void* A, int32_t lda, const void* W, float* slab, size_t slab_bytes,
+                        int32_t* splits, int32_t M, int32_t N, int32_t K, int32_t dtype, void* stream);
 
 /* One DDIM update for a batch of rows with optional classifier-free guidance:
  * DDIMScheduler.get_epsilon (ddim.py:561-587), apply_classifier_free_guidance

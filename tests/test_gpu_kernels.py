@@ -3,6 +3,7 @@ same operation (fp32: max-abs tolerances written at each check; bf16: against th
 of the bf16-rounded inputs)."""
 
 import ctypes as C
+import functools
 import math
 
 import pytest
@@ -81,18 +82,23 @@ def test_norm_modulate(hip, dtype, kind, dim):
         assert (y.float().cpu() - ref).abs().max() <= tol, (kind, dim, mod)
 
 
-def _gemm(hip, A, W, W2, bias, bias2, gate, out, epi):
+def _gemm(hip, A, W, W2, bias, bias2, gate, out, epi, ws=None):
     M, K = A.shape
     N = W.shape[0]
     hip.check(hip.lib.lcmhip_gemm(hip.ptr(A), A.stride(0), hip.ptr(W), hip.ptr(W2), hip.ptr(bias), hip.ptr(bias2),
-                                  hip.ptr(gate), hip.ptr(out), out.stride(0), M, N, K, epi, hip.dtype_code(A.dtype), _st(hip)))
+                                  hip.ptr(gate), hip.ptr(out), out.stride(0), M, N, K, epi, hip.dtype_code(A.dtype),
+                                  hip.ptr(ws), 0 if ws is None else ws.numel() * 4, _st(hip)))
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M", [1, 17, 50, 64, 100, 128, 200])
 @pytest.mark.parametrize("N,K", [(256, 256), (1024, 2048), (768, 256), (2048, 5632)])
-def test_gemm_epilogues(hip, dtype, M, N, K):
+@pytest.mark.parametrize("split", [False, True])
+def test_gemm_epilogues(hip, dtype, M, N, K, split):
     torch.manual_seed(M * 1000 + N + K)
+    ws = torch.empty(12 * M * N, device="cuda") if split else None
+    _gemm = functools.partial(globals()["_gemm"], ws=ws)   # same calls, optional split-K scratch
+
     A = torch.randn(M, K).cuda().to(dtype)
     W = (torch.randn(N, K) / math.sqrt(K)).cuda().to(dtype)
     W2 = (torch.randn(N, K) / math.sqrt(K)).cuda().to(dtype)
@@ -143,7 +149,7 @@ def test_gemm_rejects_bad_shapes(hip):
     A = torch.zeros(4, 100, device="cuda")
     W = torch.zeros(64, 100, device="cuda")
     out = torch.zeros(4, 64, device="cuda")
-    with pytest.raises(RuntimeError, match="128-byte"):
+    with pytest.raises(RuntimeError, match="512-byte"):
         _gemm(hip, A, W, None, None, None, None, out, hip.EPI_STORE)
 
 
@@ -203,3 +209,46 @@ def test_attention(hip, dtype, causal, s, base):
     ref = sdpa(qh, kh, vh, None, mask).transpose(1, 2).reshape(n_docs * s, d)
     tol = 2e-5 if dtype == torch.float32 else 2e-2
     assert (out.float().cpu() - ref).abs().max() <= tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("mode", ["plain", "extra_const", "dup_init"])
+def test_gemm_partial_residual_norm(hip, dtype, mode):
+    """Split-K slab -> fused residual update + RMS norm + modulation."""
+    torch.manual_seed(11)
+    M, N, K = 64, 1024, 2048
+    rows_total = M if mode == "plain" else 2 * M
+    A = torch.randn(M, K).cuda().to(dtype)
+    W = (torch.randn(N, K) / math.sqrt(K)).cuda().to(dtype)
+    bias = torch.randn(N).cuda().to(dtype)
+    gate, const = torch.randn(N).cuda(), torch.randn(N).cuda()
+    w = (1 + 0.1 * torch.randn(N)).cuda().to(dtype)
+    shift, scale = (0.3 * torch.randn(N)).cuda(), (0.3 * torch.randn(N)).cuda()
+    x0 = torch.randn(rows_total, N).cuda()
+    slab = torch.empty(12 * M * N, device="cuda")
+    splits = C.c_int32(0)
+    hip.check(hip.lib.lcmhip_gemm_partial(hip.ptr(A), K, hip.ptr(W), hip.ptr(slab), slab.numel() * 4, C.byref(splits),
+                                          M, N, K, hip.dtype_code(dtype), _st(hip)))
+    assert splits.value >= 2
+    lin = (A.double() @ W.double().T + bias.double()).cpu()
+    x = x0.clone()
+    y = torch.empty(rows_total, N, device="cuda", dtype=dtype)
+    rows_norm = M if mode == "extra_const" else rows_total
+    hip.check(hip.lib.lcmhip_residual_norm(
+        hip.ptr(x), hip.ptr(slab), splits.value, M, hip.ptr(bias), hip.ptr(gate),
+        hip.ptr(const) if mode == "extra_const" else None, int(mode == "dup_init"), int(mode == "dup_init"),
+        hip.ptr(w), None, hip.ptr(shift), hip.ptr(scale), hip.ptr(y), rows_total, rows_norm, N, 1, 1e-5,
+        hip.dtype_code(dtype), _st(hip)))
+    g = gate.double().cpu()
+    if mode == "plain":
+        ref_x = x0.double().cpu() + g * lin
+    elif mode == "extra_const":
+        ref_x = x0.double().cpu() + torch.cat([g * lin, (g * const.double().cpu()).expand(M, N)])
+    else:
+        ref_x = torch.cat([g * lin, g * lin])
+    tol = 2e-4 if dtype == torch.float32 else 3e-3
+    assert (x.double().cpu() - ref_x).abs().max() <= tol * max(1.0, float(ref_x.abs().max()))
+    xr = ref_x[:rows_norm]
+    ref_y = xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-5) * w.double().cpu() * (1 + scale.double().cpu()) + shift.double().cpu()
+    tol_y = 1e-4 if dtype == torch.float32 else 4e-2
+    assert (y[:rows_norm].double().cpu() - ref_y).abs().max() <= tol_y
