@@ -12,6 +12,7 @@
 // a lane holds 4 consecutive output columns of one row (vector bias/gate loads, vector stores).
 //   bf16 operands: v_mfma_f32_16x16x32_bf16;  f32 operands: v_mfma_f32_16x16x4_f32 (exact fp32).
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 
@@ -19,6 +20,7 @@ namespace lcmhip {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;   // native vector: stays in registers (HIP's uint4 is a struct)
 
 template <typename T>
 struct Mma;
@@ -41,6 +43,16 @@ struct Mma<float> {
     }
 };
 
+// Compile-time loop: f(std::integral_constant<int, I>) for I in [0, N).  Array indices are then
+// constants in the source itself, so register arrays never fall back to scratch memory.
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 constexpr int kChunkBytes = 512;             // bytes of K per tile row per chunk
 constexpr int kRowBytes = kChunkBytes + 16;  // padded LDS row
 constexpr int EPI_PARTIAL = 100;             // internal: raw fp32 partial tile to the split-K slab
@@ -50,7 +62,6 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs p) {
     constexpr bool DUAL = (EPI == LCMHIP_EPI_SWIGLU);
     constexpr int BM = 32 * WM, BNR = 64 * WN;   // activation rows / weight rows per tile
     constexpr int R = BM + BNR;
-    constexpr int NCH = R / 8;                   // 16-byte pieces per lane per chunk
     constexpr int KSTEP_BYTES = 4 * Mma<T>::kLaneBytes;
     constexpr int KSTEPS = kChunkBytes / KSTEP_BYTES;
     static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -68,30 +79,50 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs p) {
     const int c_begin = blockIdx.y * cps;
     const int c_end = min(nchunks, c_begin + cps);
 
-    const char* src[NCH];
-    int dst[NCH];
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int q = tid + i * 256;
-        const int row = q >> 5, c = q & 31;
-        const char* base;
-        if (row < BM) {
-            int m = m0 + row;
-            m = m < p.M ? m : p.M - 1;
-            base = reinterpret_cast<const char*>(p.A) + (size_t)m * p.lda * sizeof(T);
-        } else {
-            const int r = row - BM;                 // weight row inside the tile
-            if constexpr (DUAL) {
-                // each wave's 64 weight rows = 32 gate rows followed by the 32 inner rows of the same columns
-                const int w = r >> 6, rr = r & 63;
-                const int col = blockIdx.x * (BNR / 2) + w * 32 + (rr & 31);
-                base = reinterpret_cast<const char*>(rr < 32 ? p.W : p.W2) + (size_t)col * kbytes;
-            } else {
-                base = reinterpret_cast<const char*>(p.W) + (size_t)(blockIdx.x * BNR + r) * kbytes;
-            }
-        }
-        src[i] = base + c * 16 + (size_t)c_begin * kChunkBytes;
-        dst[i] = row * kRowBytes + c * 16;
+    // Lane (r0 = tid / 32, c = tid % 32) moves the 16-byte piece c of tile rows r0, r0 + 8, r0 + 16, ...:
+    // 32 consecutive lanes cover one 512-byte row segment.  Row addresses are recomputed from two
+    // scalars per operand (no per-piece pointer arrays, which the compiler would keep in scratch).
+    constexpr int NA = BM / 8, NW = BNR / 8;
+    const int r0 = tid >> 5;
+    const size_t col_off = (size_t)(tid & 31) * 16 + (size_t)c_begin * kChunkBytes;
+    const char* a_base = reinterpret_cast<const char*>(p.A) + col_off;
+    const size_t a_stride = (size_t)p.lda * sizeof(T);
+    const char* w_base;
+    const char* w2_base = nullptr;
+    if constexpr (DUAL) {
+        w_base = reinterpret_cast<const char*>(p.W) + (size_t)(blockIdx.x * (BNR / 2) + r0) * kbytes + col_off;
+        w2_base = reinterpret_cast<const char*>(p.W2) + (size_t)(blockIdx.x * (BNR / 2) + r0) * kbytes + col_off;
+    } else {
+        w_base = reinterpret_cast<const char*>(p.W) + (size_t)(blockIdx.x * BNR + r0) * kbytes + col_off;
+    }
+    char* lds_dst = smem + r0 * kRowBytes + (tid & 31) * 16;
+
+    u32x4 ra[NA], rw[NW];
+#define LCM_LOAD_CHUNK(OFF)                                                                              \
+    {                                                                                                    \
+        const size_t off_ = (OFF);                                                                       \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                 \
+            int m = m0 + r0 + 8 * i;                                                                     \
+            m = m < p.M ? m : p.M - 1;                                                                   \
+            ra[i] = *reinterpret_cast<const u32x4*>(a_base + (size_t)m * a_stride + off_);               \
+        }                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < NW; ++i) {                                                 \
+            if constexpr (DUAL) {                                                                        \
+                /* tile row 8i + r0: wave group (8i) / 64; inside it rows 0..31 = gate, 32..63 = inner */ \
+                const int grp = (8 * i) >> 6, rr = (8 * i) & 63;                                         \
+                const char* b = (rr < 32 ? w_base : w2_base) + (size_t)(grp * 32 + (rr & 31)) * kbytes;  \
+                rw[i] = *reinterpret_cast<const u32x4*>(b + off_);                                       \
+            } else {                                                                                     \
+                rw[i] = *reinterpret_cast<const u32x4*>(w_base + (size_t)(8 * i) * kbytes + off_);       \
+            }                                                                                            \
+        }                                                                                                \
+    }
+#define LCM_STORE_CHUNK()                                                                                \
+    {                                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i)                                                   \
+            *reinterpret_cast<u32x4*>(lds_dst + (8 * i) * kRowBytes) = ra[i];                            \
+        _Pragma("unroll") for (int i = 0; i < NW; ++i)                                                   \
+            *reinterpret_cast<u32x4*>(lds_dst + (BM + 8 * i) * kRowBytes) = rw[i];                       \
     }
 
     f32x4 acc[4][2];
@@ -100,31 +131,24 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs p) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    uint4 regs[NCH];
-    if (c_begin < c_end) {
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) regs[i] = *reinterpret_cast<const uint4*>(src[i]);
-    }
+    LCM_LOAD_CHUNK(0);   // every split owns at least one chunk (see make_plan)
     const int frow = lane & 15;
     const int fk = (lane >> 4) * Mma<T>::kLaneBytes;
+    const char* w_frag = smem + (BM + wn * 64 + frow) * kRowBytes + fk;
+    const char* x_frag = smem + (wm * 32 + frow) * kRowBytes + fk;
     for (int ch = c_begin; ch < c_end; ++ch) {
         if (ch != c_begin) __syncthreads();   // previous chunk fully consumed before it is overwritten
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) *reinterpret_cast<uint4*>(smem + dst[i]) = regs[i];
+        LCM_STORE_CHUNK();
         __syncthreads();
-        if (ch + 1 < c_end) {
-            const size_t off = (size_t)(ch + 1 - c_begin) * kChunkBytes;
-#pragma unroll
-            for (int i = 0; i < NCH; ++i) regs[i] = *reinterpret_cast<const uint4*>(src[i] + off);
-        }
+        if (ch + 1 < c_end) LCM_LOAD_CHUNK((size_t)(ch + 1 - c_begin) * kChunkBytes);
 #pragma unroll 2
         for (int ks = 0; ks < KSTEPS; ++ks) {
-            const int kb = ks * KSTEP_BYTES + fk;
+            const int kb = ks * KSTEP_BYTES;
             typename Mma<T>::Frag w[4], x[2];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) w[t] = Mma<T>::ld(smem + (BM + wn * 64 + t * 16 + frow) * kRowBytes + kb);
+            for (int t = 0; t < 4; ++t) w[t] = Mma<T>::ld(w_frag + t * 16 * kRowBytes + kb);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) x[t] = Mma<T>::ld(smem + (wm * 32 + t * 16 + frow) * kRowBytes + kb);
+            for (int t = 0; t < 2; ++t) x[t] = Mma<T>::ld(x_frag + t * 16 * kRowBytes + kb);
 #pragma unroll
             for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
@@ -234,6 +258,7 @@ __global__ __launch_bounds__(256) void k_splitk_finish(GemmArgs p, int splits) {
         const int m = (int)(i / n4), n = (int)(i % n4) * 4;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         if (m < p.M) {
+#pragma unroll 4
             for (int s = 0; s < splits; ++s) {
                 const float4 t = *reinterpret_cast<const float4*>(p.partial + ((size_t)s * p.M + m) * p.N + n);
                 v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
