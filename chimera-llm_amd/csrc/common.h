@@ -182,6 +182,16 @@ int launch_norm_modulate(float* x, const void* w, const void* b, const float* sh
                          const Pending* pend, hipStream_t st);
 int launch_attention(const void* q, const void* kc, const void* vc, const int32_t* slot_map, void* out, int n_docs,
                      int s, int n_heads, int cap, int base_keys, int causal, int dtype, hipStream_t st);
+// Query source of the attention kernel: a finished (rows, d) tensor, or the split-K slab of the q projection.
+struct AttnQ {
+    const void* q;
+    const float* partial;
+    int splits;
+    int rows;
+    const void* bias;
+};
+int launch_attention_q(const AttnQ& qa, const void* kc, const void* vc, const int32_t* slot_map, void* out, int n_docs,
+                       int s, int n_heads, int cap, int base_keys, int causal, int dtype, hipStream_t st);
 
 struct DdimScalars {
     float sqrt_a_t, sqrt_b_t;        // sqrt(alpha_prod_t), sqrt(1 - alpha_prod_t)

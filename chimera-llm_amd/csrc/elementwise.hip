@@ -156,6 +156,28 @@ __global__ __launch_bounds__(256) void k_norm_modulate(float* __restrict__ x, co
         }
     }
     if (row >= rows_norm) return;   // uniform per workgroup
+    // norm weight / bias / modulation for this lane's columns: requested now, consumed after the reduction
+    float pw[MAXV][4], pb[MAXV][4], psc[MAXV][4], psh[MAXV][4];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = threadIdx.x + i * 256;
+        if (c < nv) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                pw[i][j] = Elem<T>::load(w + c * 4 + j);
+                pb[i][j] = (KIND == LCMHIP_NORM_LAYERNORM && b != nullptr) ? Elem<T>::load(b + c * 4 + j) : 0.f;
+            }
+            if (scale != nullptr) {
+                const float4 a = *reinterpret_cast<const float4*>(scale + c * 4);
+                const float4 h = *reinterpret_cast<const float4*>(shift + c * 4);
+                psc[i][0] = a.x; psc[i][1] = a.y; psc[i][2] = a.z; psc[i][3] = a.w;
+                psh[i][0] = h.x; psh[i][1] = h.y; psh[i][2] = h.z; psh[i][3] = h.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { psc[i][j] = 0.f; psh[i][j] = 0.f; }
+            }
+        }
+    }
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
@@ -194,10 +216,8 @@ __global__ __launch_bounds__(256) void k_norm_modulate(float* __restrict__ x, co
             float o[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float t = (o[j] - mean) * rstd * Elem<T>::load(w + col + j);
-                if (KIND == LCMHIP_NORM_LAYERNORM && b != nullptr) t += Elem<T>::load(b + col + j);
-                if (scale != nullptr) t = t * (1.f + scale[col + j]) + shift[col + j];
-                o[j] = t;
+                float t = (o[j] - mean) * rstd * pw[i][j] + pb[i][j];
+                o[j] = t * (1.f + psc[i][j]) + psh[i][j];
             }
             if (sizeof(T) == 4) {
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(yr) + col) = make_float4(o[0], o[1], o[2], o[3]);

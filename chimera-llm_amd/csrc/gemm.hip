@@ -12,6 +12,7 @@
 // a lane holds 4 consecutive output columns of one row (vector bias/gate loads, vector stores).
 //   bf16 operands: v_mfma_f32_16x16x32_bf16;  f32 operands: v_mfma_f32_16x16x4_f32 (exact fp32).
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -57,10 +58,12 @@ constexpr int kChunkBytes = 512;             // bytes of K per tile row per chun
 constexpr int kRowBytes = kChunkBytes + 16;  // padded LDS row
 constexpr int EPI_PARTIAL = 100;             // internal: raw fp32 partial tile to the split-K slab
 
-template <typename T, int WM, int WN, int EPI>
+// WM x WN waves; each wave owns 32 activation rows x (16 * TN) weight rows.
+template <typename T, int WM, int WN, int TN, int EPI>
 __global__ __launch_bounds__(256) void k_gemm(GemmArgs p) {
     constexpr bool DUAL = (EPI == LCMHIP_EPI_SWIGLU);
-    constexpr int BM = 32 * WM, BNR = 64 * WN;   // activation rows / weight rows per tile
+    constexpr int WR = 16 * TN;                  // weight rows per wave
+    constexpr int BM = 32 * WM, BNR = WR * WN;   // activation rows / weight rows per tile
     constexpr int R = BM + BNR;
     constexpr int KSTEP_BYTES = 4 * Mma<T>::kLaneBytes;
     constexpr int KSTEPS = kChunkBytes / KSTEP_BYTES;
@@ -108,9 +111,9 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs p) {
         }                                                                                                \
         _Pragma("unroll") for (int i = 0; i < NW; ++i) {                                                 \
             if constexpr (DUAL) {                                                                        \
-                /* tile row 8i + r0: wave group (8i) / 64; inside it rows 0..31 = gate, 32..63 = inner */ \
-                const int grp = (8 * i) >> 6, rr = (8 * i) & 63;                                         \
-                const char* b = (rr < 32 ? w_base : w2_base) + (size_t)(grp * 32 + (rr & 31)) * kbytes;  \
+                /* tile row 8i + r0 belongs to wave (8i) / WR; a wave's first WR/2 rows = gate, rest = inner */ \
+                const int grp = (8 * i) / WR, rr = (8 * i) % WR;                                         \
+                const char* b = (rr < WR / 2 ? w_base : w2_base) + (size_t)(grp * (WR / 2) + (rr % (WR / 2))) * kbytes; \
                 rw[i] = *reinterpret_cast<const u32x4*>(b + off_);                                       \
             } else {                                                                                     \
                 rw[i] = *reinterpret_cast<const u32x4*>(w_base + (size_t)(8 * i) * kbytes + off_);       \
@@ -125,16 +128,16 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs p) {
             *reinterpret_cast<u32x4*>(lds_dst + (BM + 8 * i) * kRowBytes) = rw[i];                       \
     }
 
-    f32x4 acc[4][2];
+    f32x4 acc[TN][2];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < TN; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     LCM_LOAD_CHUNK(0);   // every split owns at least one chunk (see make_plan)
     const int frow = lane & 15;
     const int fk = (lane >> 4) * Mma<T>::kLaneBytes;
-    const char* w_frag = smem + (BM + wn * 64 + frow) * kRowBytes + fk;
+    const char* w_frag = smem + (BM + wn * WR + frow) * kRowBytes + fk;
     const char* x_frag = smem + (wm * 32 + frow) * kRowBytes + fk;
     for (int ch = c_begin; ch < c_end; ++ch) {
         if (ch != c_begin) __syncthreads();   // previous chunk fully consumed before it is overwritten
@@ -144,13 +147,13 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs p) {
 #pragma unroll 2
         for (int ks = 0; ks < KSTEPS; ++ks) {
             const int kb = ks * KSTEP_BYTES;
-            typename Mma<T>::Frag w[4], x[2];
+            typename Mma<T>::Frag w[TN], x[2];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) w[t] = Mma<T>::ld(w_frag + t * 16 * kRowBytes + kb);
+            for (int t = 0; t < TN; ++t) w[t] = Mma<T>::ld(w_frag + t * 16 * kRowBytes + kb);
 #pragma unroll
             for (int t = 0; t < 2; ++t) x[t] = Mma<T>::ld(x_frag + t * 16 * kRowBytes + kb);
 #pragma unroll
-            for (int tn = 0; tn < 4; ++tn)
+            for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                 for (int tm = 0; tm < 2; ++tm) acc[tn][tm] = Mma<T>::mma(w[tn], x[tm], acc[tn][tm]);
         }
@@ -161,8 +164,8 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs p) {
     if constexpr (EPI == EPI_PARTIAL) {
         float* slab = p.partial + (size_t)blockIdx.y * p.M * p.N;
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn) {
-            const int n = blockIdx.x * BNR + wn * 64 + tn * 16 + quad;
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = blockIdx.x * BNR + wn * WR + tn * 16 + quad;
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm) {
                 const int m = m0 + wm * 32 + tm * 16 + (lane & 15);
@@ -175,11 +178,11 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs p) {
     } else {
         const T* bias = reinterpret_cast<const T*>(p.bias);
         const T* bias2 = reinterpret_cast<const T*>(p.bias2);
-        constexpr int TN = DUAL ? 2 : 4;
+        constexpr int TNO = DUAL ? TN / 2 : TN;   // output column tiles per wave
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int n = DUAL ? blockIdx.x * (BNR / 2) + wn * 32 + tn * 16 + quad
-                               : blockIdx.x * BNR + wn * 64 + tn * 16 + quad;
+        for (int tn = 0; tn < TNO; ++tn) {
+            const int n = DUAL ? blockIdx.x * (BNR / 2) + wn * (WR / 2) + tn * 16 + quad
+                               : blockIdx.x * BNR + wn * WR + tn * 16 + quad;
             float bv[4] = {0.f, 0.f, 0.f, 0.f}, bv2[4] = {0.f, 0.f, 0.f, 0.f}, gv[4] = {1.f, 1.f, 1.f, 1.f};
             if (bias) {
 #pragma unroll
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs p) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float g = v[r];
-                            const float in = acc[tn + 2][tm][r] + bv2[r];
+                            const float in = acc[tn + TN / 2][tm][r] + bv2[r];
                             v[r] = in * (g / (1.f + __expf(-g)));
                         }
                     }
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(256) void k_splitk_finish(GemmArgs p, int splits) {
 
 // ---- host-side dispatch -------------------------------------------------------------------------------
 struct Plan {
-    int wm, wn;        // wave grid
+    int wm, wn, tn;    // wave grid and weight tiles per wave
     int n_tiles, m_tiles, splits;
 };
 
@@ -308,19 +311,19 @@ static Plan make_plan(const GemmArgs& a, bool may_split) {
     const bool dual = a.epilogue == LCMHIP_EPI_SWIGLU;
     const int wrows = dual ? 2 * a.N : a.N;   // weight rows streamed
     Plan pl{};
-    if (rows <= 32 && wrows % 256 == 0) { pl.wm = 1; pl.wn = 4; }
-    else if (rows <= 64 && wrows % 128 == 0) { pl.wm = 2; pl.wn = 2; }
-    else { pl.wm = 4; pl.wn = 1; }
-    const int bm = 32 * pl.wm, bnr = 64 * pl.wn;
+    if (rows <= 32 && wrows % 256 == 0) { pl.wm = 1; pl.wn = 4; pl.tn = 4; }         // 32 x 256
+    else if (rows <= 64 && wrows % 128 == 0 && wrows >= 128 * 192) { pl.wm = 2; pl.wn = 2; pl.tn = 4; }   // 64 x 128
+    else { pl.wm = 2; pl.wn = 2; pl.tn = 2; }                                        // 64 x 64, two per CU
+    const int bm = 32 * pl.wm, bnr = 16 * pl.tn * pl.wn;
     pl.n_tiles = wrows / bnr;
     pl.m_tiles = (rows + bm - 1) / bm;
     pl.splits = 1;
     if (may_split) {
         const int nchunks = (int)((size_t)a.K * dtype_size(a.dtype) / kChunkBytes);
         const int tiles = pl.n_tiles * pl.m_tiles;
-        // aim at ~2 workgroups' worth of loads per CU across the 256 CUs, at least 2 chunks per split
-        // only when there are enough chunks to share
-        int s = (384 + tiles - 1) / tiles;
+        // enough workgroups to put two on every CU, every split at least one chunk
+        static const int target = [] { const char* e = getenv("LCMHIP_SPLIT_TARGET"); return e ? atoi(e) : 512; }();
+        int s = (target + tiles - 1) / tiles;
         s = std::min(s, nchunks);
         s = std::min(s, a.max_splits > 0 ? a.max_splits : 64);
         pl.splits = std::max(1, s);
@@ -331,16 +334,16 @@ static Plan make_plan(const GemmArgs& a, bool may_split) {
     return pl;
 }
 
-template <typename T, int WM, int WN>
+template <typename T, int WM, int WN, int TN>
 static int launch_cfg(const GemmArgs& a, const Plan& pl, int epi, hipStream_t st) {
     dim3 grid(pl.n_tiles, pl.splits, pl.m_tiles), block(256);
     switch (epi) {
-        case LCMHIP_EPI_STORE: hipLaunchKernelGGL((k_gemm<T, WM, WN, LCMHIP_EPI_STORE>), grid, block, 0, st, a); break;
-        case LCMHIP_EPI_STORE_F32: hipLaunchKernelGGL((k_gemm<T, WM, WN, LCMHIP_EPI_STORE_F32>), grid, block, 0, st, a); break;
-        case LCMHIP_EPI_RELU: hipLaunchKernelGGL((k_gemm<T, WM, WN, LCMHIP_EPI_RELU>), grid, block, 0, st, a); break;
-        case LCMHIP_EPI_SWIGLU: hipLaunchKernelGGL((k_gemm<T, WM, WN, LCMHIP_EPI_SWIGLU>), grid, block, 0, st, a); break;
-        case LCMHIP_EPI_RESID: hipLaunchKernelGGL((k_gemm<T, WM, WN, LCMHIP_EPI_RESID>), grid, block, 0, st, a); break;
-        case EPI_PARTIAL: hipLaunchKernelGGL((k_gemm<T, WM, WN, EPI_PARTIAL>), grid, block, 0, st, a); break;
+        case LCMHIP_EPI_STORE: hipLaunchKernelGGL((k_gemm<T, WM, WN, TN, LCMHIP_EPI_STORE>), grid, block, 0, st, a); break;
+        case LCMHIP_EPI_STORE_F32: hipLaunchKernelGGL((k_gemm<T, WM, WN, TN, LCMHIP_EPI_STORE_F32>), grid, block, 0, st, a); break;
+        case LCMHIP_EPI_RELU: hipLaunchKernelGGL((k_gemm<T, WM, WN, TN, LCMHIP_EPI_RELU>), grid, block, 0, st, a); break;
+        case LCMHIP_EPI_SWIGLU: hipLaunchKernelGGL((k_gemm<T, WM, WN, TN, LCMHIP_EPI_SWIGLU>), grid, block, 0, st, a); break;
+        case LCMHIP_EPI_RESID: hipLaunchKernelGGL((k_gemm<T, WM, WN, TN, LCMHIP_EPI_RESID>), grid, block, 0, st, a); break;
+        case EPI_PARTIAL: hipLaunchKernelGGL((k_gemm<T, WM, WN, TN, EPI_PARTIAL>), grid, block, 0, st, a); break;
         default: return fail(LCMHIP_ERR_INVALID, "gemm: unknown epilogue");
     }
     LCM_HIP_CHECK(hipGetLastError());
@@ -349,9 +352,9 @@ static int launch_cfg(const GemmArgs& a, const Plan& pl, int epi, hipStream_t st
 
 template <typename T>
 static int launch_plan(const GemmArgs& a, const Plan& pl, int epi, hipStream_t st) {
-    if (pl.wm == 1) return launch_cfg<T, 1, 4>(a, pl, epi, st);
-    if (pl.wm == 2) return launch_cfg<T, 2, 2>(a, pl, epi, st);
-    return launch_cfg<T, 4, 1>(a, pl, epi, st);
+    if (pl.wm == 1) return launch_cfg<T, 1, 4, 4>(a, pl, epi, st);
+    if (pl.tn == 4) return launch_cfg<T, 2, 2, 4>(a, pl, epi, st);
+    return launch_cfg<T, 2, 2, 2>(a, pl, epi, st);
 }
 
 template <typename T>

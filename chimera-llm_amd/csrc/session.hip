@@ -96,7 +96,7 @@ struct NormW { const void* w = nullptr; const void* b = nullptr; };
 struct AttnW { Lin q, k, v, o; };
 struct FfnW { Lin gate, inner, out; };
 struct CtxLayer { NormW sa_norm, ffn_norm; AttnW sa; FfnW ffn; };
-struct DenLayer { NormW sa_norm, ca_norm, ffn_norm; AttnW sa, ca; FfnW ffn; Lin mod; };
+struct DenLayer { NormW sa_norm, ca_norm, ffn_norm; AttnW sa, ca; FfnW ffn; Lin mod; Lin ov; };   // ov: optional folded output_proj * v_proj
 
 }  // namespace lcmhip
 
@@ -360,10 +360,11 @@ static int gemm(lcmhip_session* s, const char* tag, const void* A, int lda, cons
 
 // Product left in slab_p for the next norm kernel to fold into the residual stream.
 static int gemm_pending(lcmhip_session* s, const char* tag, const void* A, int lda, const Lin& W, const float* gate,
-                        int M, Pending* pend, hipStream_t st) {
+                        int M, Pending* pend, hipStream_t st, float* slab = nullptr) {
     GemmArgs a = gemm_args(s, A, lda, W, nullptr, M, LCMHIP_EPI_STORE_F32);
     a.bias = nullptr;
-    a.partial = s->slab_p; a.partial_bytes = s->slab_bytes;
+    if (slab == nullptr) slab = s->slab_p;
+    a.partial = slab; a.partial_bytes = s->slab_bytes;
     double bytes, flops;
     gemm_cost(a, 0.0, &bytes, &flops);
     int splits = 0;
@@ -372,7 +373,7 @@ static int gemm_pending(lcmhip_session* s, const char* tag, const void* A, int l
         LCM_TRY(launch_gemm_partial(a, &splits, st));
     }
     *pend = Pending{};
-    pend->partial = s->slab_p;
+    pend->partial = slab;
     pend->splits = splits;
     pend->M = M;
     pend->bias = W.b;
@@ -479,6 +480,9 @@ int lcmhip_model_finalize(lcmhip_model* m) {
         LCM_TRY(get_attn(m, p + ".cross_attention", dm, d.denoiser.out_proj_bias != 0, &L.ca));
         LCM_TRY(get_ffn(m, p + ".ffn", dm, d.denoiser, &L.ffn));
         LCM_TRY(get_lin(m, p + ".modulator.fc", 9 * dm, dm, true, &L.mod));
+        // optional derived weight: self-attention over one position is output_proj(v_proj(h)) = h W_ov^T + b_ov
+        L.ov = Lin{};
+        if (m->tensors.count(p + ".self_attn.ov_proj.weight")) LCM_TRY(get_lin(m, p + ".self_attn.ov_proj", dm, dm, true, &L.ov));
     }
     LCM_TRY(get_norm(m, "denoiser.layer_norm", dm, d.denoiser.norm_kind, &m->den_final));
     m->finalized = true;
@@ -785,17 +789,24 @@ int lcmhip_denoise(lcmhip_session* s, const float* noise, float* out, float* lat
             const float* mod = mod_step + (size_t)l * 9 * dm;
             // self-attention over a single position: softmax == 1, so the block is output_proj(v_proj(h))
             LCM_TRY(norm(s, "den.norm_mod", s->xres, Ly.sa_norm, mod, mod + dm, s->act_a, rows, rows, td.norm_kind, &pend, st));
-            LCM_TRY(gemm(s, "den.self_v", s->act_a, dm, Ly.sa.v, nullptr, nullptr, s->act_v, dm, rows, LCMHIP_EPI_STORE, st));
-            LCM_TRY(gemm_pending(s, "den.self_o", s->act_v, dm, Ly.sa.o, mod + 2 * dm, rows, &pend, st));
+            if (Ly.ov.w != nullptr) {
+                LCM_TRY(gemm_pending(s, "den.self_ov", s->act_a, dm, Ly.ov, mod + 2 * dm, rows, &pend, st));
+            } else {
+                LCM_TRY(gemm(s, "den.self_v", s->act_a, dm, Ly.sa.v, nullptr, nullptr, s->act_v, dm, rows, LCMHIP_EPI_STORE, st));
+                LCM_TRY(gemm_pending(s, "den.self_o", s->act_v, dm, Ly.sa.o, mod + 2 * dm, rows, &pend, st));
+            }
             // cross-attention: conditional rows attend to [zero slot, context]; unconditional rows only
             // see the zero slot, whose value is a per-layer constant
             LCM_TRY(norm(s, "den.norm_mod", s->xres, Ly.ca_norm, mod + 3 * dm, mod + 4 * dm, s->act_a, rows, B, td.norm_kind, &pend, st));
-            LCM_TRY(gemm(s, "den.cross_q", s->act_a, dm, Ly.ca.q, nullptr, nullptr, s->act_q, dm, B, LCMHIP_EPI_STORE, st));
+            Pending qp;   // the q projection stays in slab_q; the attention kernel sums it
+            LCM_TRY(gemm_pending(s, "den.cross_q", s->act_a, dm, Ly.ca.q, nullptr, B, &qp, st, s->slab_q));
             {
-                ProfScope ps(&s->prof, "den.cross_attn", 2.0 * B * (double)nkeys * dm * es + 2.0 * B * dm * es,
+                AttnQ qa{};
+                qa.partial = qp.partial; qa.splits = qp.splits; qa.rows = B; qa.bias = qp.bias;
+                ProfScope ps(&s->prof, "den.cross_attn", 2.0 * B * (double)nkeys * dm * es + B * dm * (es + 4.0 * qp.splits),
                              4.0 * B * (double)nkeys * dm, st);
-                LCM_TRY(launch_attention(s->act_q, s->cross_k + l * cross_layer, s->cross_v + l * cross_layer, s->slot_map,
-                                         s->act_o, B, 1, td.num_heads, s->cap + 1, nkeys, 0, d.dtype, st));
+                LCM_TRY(launch_attention_q(qa, s->cross_k + l * cross_layer, s->cross_v + l * cross_layer, s->slot_map,
+                                           s->act_o, B, 1, td.num_heads, s->cap + 1, nkeys, 0, d.dtype, st));
             }
             LCM_TRY(gemm_pending(s, "den.cross_o", s->act_o, dm, Ly.ca.o, mod + 5 * dm, B, &pend, st));
             pend.extra_const = s->uconst + (size_t)l * dm;

@@ -267,6 +267,15 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
         self._spec = parameter_spec(config)
         self._params: Dict[str, Tensor] = {
             name: torch.empty(shape, dtype=dtype, device=device) for name, shape, _ in self._spec}
+        # derived tensors: the denoiser's self-attention always sees one position, where softmax == 1 and the
+        # block collapses to output_proj(v_proj(h)); W_ov = W_o W_v and b_ov = W_o b_v + b_o are folded once per
+        # weight load (by the library's own GEMM) so that a diffusion step streams one matrix instead of two
+        d = config.model_dim
+        self._derived: Dict[str, Tensor] = {}
+        for i in range(config.denoiser.num_layers):
+            self._derived[f"denoiser.layers.{i}.self_attn.ov_proj.weight"] = torch.empty((d, d), dtype=dtype, device=device)
+            self._derived[f"denoiser.layers.{i}.self_attn.ov_proj.bias"] = torch.empty((d,), dtype=dtype, device=device)
+        self._handle = None
         self.init_parameters(seed if seed is not None else 0)
         self.sonar_normalizer = SonarNormalizer(SonarNormalizerConfig(dim=config.sonar_embed_dim), device=device, dtype=dtype)
         # the normalizer's buffers ARE the model's tensors (one storage, like a registered submodule)
@@ -275,6 +284,7 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
         self.noise_scheduler = DDIMScheduler(config.noise_scheduler)
         self._handle = C.c_void_p()
         self._bind()
+        self._refresh_derived()
         self._session_pool: List[DeviceSession] = []
 
     # ---- parameters ---------------------------------------------------------------------------------
@@ -295,6 +305,26 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
                     t.zero_()
                 else:
                     t.copy_(torch.randn(shape, generator=g, device=t.device, dtype=torch.float32) * std)
+        self._refresh_derived()
+
+    def _refresh_derived(self) -> None:
+        if not getattr(self, "_handle", None):
+            return
+        P, code, st = self._params, _hip.dtype_code(self.dtype), _hip.stream_ptr(self.device)
+        d = self.config.model_dim
+        for i in range(self.config.denoiser.num_layers):
+            p = f"denoiser.layers.{i}.self_attn"
+            wo, wv_t = P[f"{p}.output_proj.weight"], P[f"{p}.v_proj.weight"].t().contiguous()
+            bo = P.get(f"{p}.output_proj.bias")
+            # W_ov[i][j] = sum_k W_o[i][k] W_v[k][j]  ==  lcmhip_gemm(A = W_o, W = W_v^T)
+            _hip.check(_hip.lib.lcmhip_gemm(_hip.ptr(wo), d, _hip.ptr(wv_t), None, None, None, None,
+                                            _hip.ptr(self._derived[f"{p}.ov_proj.weight"]), d, d, d, d, _hip.EPI_STORE,
+                                            code, None, 0, st))
+            # b_ov = W_o b_v + b_o
+            _hip.check(_hip.lib.lcmhip_gemm(_hip.ptr(P[f"{p}.v_proj.bias"]), d, _hip.ptr(wo), None, _hip.ptr(bo), None, None,
+                                            _hip.ptr(self._derived[f"{p}.ov_proj.bias"]), d, 1, d, d, _hip.EPI_STORE,
+                                            code, None, 0, st))
+        torch.cuda.current_stream(self.device).synchronize()   # wv_t temporaries may be freed after this
 
     def state_dict(self) -> Dict[str, Tensor]:
         return self._params
@@ -310,6 +340,7 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
                 if tuple(sd[k].shape) != tuple(dst.shape):
                     raise RuntimeError(f"load_state_dict: shape mismatch for {k}: {tuple(sd[k].shape)} vs {tuple(dst.shape)}")
                 dst.copy_(sd[k])
+        self._refresh_derived()
 
     def num_parameters(self) -> int:
         return sum(t.numel() for n, t in self._params.items() if not n.startswith("sonar_normalizer."))
@@ -330,7 +361,7 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
                               context=tower(c.context_encoder), denoiser=tower(c.denoiser))
         _hip.check(_hip.lib.lcmhip_model_create(C.byref(desc), C.byref(self._handle)))
         code = _hip.dtype_code(self.dtype)
-        for name, t in self._params.items():
+        for name, t in list(self._params.items()) + list(self._derived.items()):
             shape = (C.c_int64 * t.dim())(*t.shape)
             _hip.check(_hip.lib.lcmhip_model_bind_weight(self._handle, name.encode(), _hip.ptr(t), code, t.dim(), shape))
         _hip.check(_hip.lib.lcmhip_model_finalize(self._handle))
