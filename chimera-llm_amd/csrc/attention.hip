@@ -3,12 +3,15 @@
 // zero-vector slot + every context position) and for the contextualizer's KV-cached causal
 // self-attention (decode: one query; prefill: a short causal block).
 //
-// One wave per (query row, head).  Lane = (key group kg = lane / 16, dim group dg = lane % 16): it
-// owns 8 of the 128 dims and walks keys kg, kg + 4, kg + 8, ... with 16-byte loads (a key or value
-// row of one head is 256 contiguous bytes = one wave-quarter), keeps an online softmax (running
-// max / sum / 8 accumulators) and never touches LDS; the 4 key groups are merged with two
-// shuffles at the end.  The query may come straight from a split-K slab (sum of partial
-// products + bias), which saves the finishing pass of the q projection.
+// Cache layout: [slot][head][position][128] -- the keys (values) of one (document, head) form one
+// contiguous stream.  One wave per (query row, head), 4 heads per workgroup.  Lane = (key slot
+// ks = lane / 4, dim group dg = lane % 4): the wave walks 16 keys at a time, the 4 lanes of a slot each
+// own 32 of the 128 dims as four 16-byte pieces interleaved so that one load instruction reads 64
+// contiguous bytes per key (4 KB contiguous per 4 instructions).  Every lane keeps an online softmax
+// (running max / sum / 32 accumulators) over its keys ks, ks + 16, ... -- no LDS -- and the 16 slots
+// are merged with shuffles at the end.  Two keys per lane are in flight per iteration (16 independent
+// 16-byte loads).  The query may come straight from a split-K slab (sum of partial products + bias),
+// which saves the finishing pass of the q projection.
 #include "common.h"
 
 namespace lcmhip {
@@ -28,89 +31,113 @@ __global__ __launch_bounds__(256) void k_attention(AttnQ qa, const T* __restrict
     const int slot = slot_map ? slot_map[doc] : doc;
     const int nkeys = base_keys + (causal ? j + 1 : 0);
     const int d = n_heads * kHeadDim;
-    const int kg = lane >> 4, dg = lane & 15;
-    const int col = head * kHeadDim + dg * 8;
+    const int ks = lane >> 2, dg = lane & 3;
+    const int col = head * kHeadDim + dg * 8;           // piece i of this lane starts at col + 32 * i
 
-    float qv[8];
+    float qv[4][8];
     if (qa.partial != nullptr) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) qv[t] = 0.f;
-#pragma unroll 4
-        for (int sp = 0; sp < qa.splits; ++sp) {
-            float t8[8];
-            load8<float>(qa.partial + ((size_t)sp * qa.rows + row) * d + col, t8);
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int t = 0; t < 8; ++t) qv[t] += t8[t];
+            for (int t = 0; t < 8; ++t) qv[i][t] = 0.f;
+#pragma unroll 2
+        for (int sp = 0; sp < qa.splits; ++sp) {
+            const float* src = qa.partial + ((size_t)sp * qa.rows + row) * d + col;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float t8[8];
+                load8<float>(src + 32 * i, t8);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) qv[i][t] += t8[t];
+            }
         }
         if (qa.bias != nullptr) {
-            float b8[8];
-            load8<T>(reinterpret_cast<const T*>(qa.bias) + col, b8);
 #pragma unroll
-            for (int t = 0; t < 8; ++t) qv[t] += b8[t];
+            for (int i = 0; i < 4; ++i) {
+                float b8[8];
+                load8<T>(reinterpret_cast<const T*>(qa.bias) + col + 32 * i, b8);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) qv[i][t] += b8[t];
+            }
         }
         // the reference rounds q to the operand dtype before the scores
         if (sizeof(T) == 2) {
 #pragma unroll
-            for (int t = 0; t < 8; ++t) qv[t] = bf16_to_f32(f32_to_bf16(qv[t]));
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) qv[i][t] = bf16_to_f32(f32_to_bf16(qv[i][t]));
         }
     } else {
-        load8<T>(reinterpret_cast<const T*>(qa.q) + (size_t)row * d + col, qv);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load8<T>(reinterpret_cast<const T*>(qa.q) + (size_t)row * d + col + 32 * i, qv[i]);
     }
     const float scale = 0.08838834764831845f;  // 128^-0.5
 #pragma unroll
-    for (int t = 0; t < 8; ++t) qv[t] *= scale;
-
-    const T* kbase = kc + ((size_t)slot * cap) * d + col;
-    const T* vbase = vc + ((size_t)slot * cap) * d + col;
-
-    float m = -INFINITY, l = 0.f, acc[8];
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int t = 0; t < 8; ++t) acc[t] = 0.f;
+        for (int t = 0; t < 8; ++t) qv[i][t] *= scale;
 
-    auto dot16 = [&](const float (&kv)[8]) {
+    const size_t hbase = ((size_t)slot * n_heads + head) * cap * kHeadDim + dg * 8;
+    const T* kbase = kc + hbase;
+    const T* vbase = vc + hbase;
+
+    float m = -INFINITY, l = 0.f, acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[i][t] = 0.f;
+
+    // score of one key: partial dot over this lane's 32 dims, summed over the slot's 4 lanes
+    auto score = [&](const float (&kv)[4][8]) {
         float p = 0.f;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) p += kv[t] * qv[t];
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) p += kv[i][t] * qv[i][t];
         p += __shfl_xor(p, 1, 64);
         p += __shfl_xor(p, 2, 64);
-        p += __shfl_xor(p, 4, 64);
-        p += __shfl_xor(p, 8, 64);
-        return p;   // identical in the 16 lanes of the key group
+        return p;
     };
-    auto absorb = [&](float sc, const float (&vv)[8]) {
+    auto absorb = [&](float sc, const float (&vv)[4][8]) {
         const float mn = fmaxf(m, sc);
         const float alpha = __expf(m - mn);
         const float p = __expf(sc - mn);
         l = l * alpha + p;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) acc[t] = acc[t] * alpha + p * vv[t];
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[i][t] = acc[i][t] * alpha + p * vv[i][t];
         m = mn;
     };
 
-    int key = kg;
-    // two keys per lane per iteration: four independent 16-byte loads in flight
-    for (; key + 4 < nkeys; key += 8) {
-        float k0[8], k1[8], v0[8], v1[8];
-        load8<T>(kbase + (size_t)key * d, k0);
-        load8<T>(kbase + (size_t)(key + 4) * d, k1);
-        load8<T>(vbase + (size_t)key * d, v0);
-        load8<T>(vbase + (size_t)(key + 4) * d, v1);
-        const float s0 = dot16(k0), s1 = dot16(k1);
+    int key = ks;
+    for (; key + 16 < nkeys; key += 32) {
+        float k0[4][8], k1[4][8], v0[4][8], v1[4][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load8<T>(kbase + (size_t)key * kHeadDim + 32 * i, k0[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load8<T>(kbase + (size_t)(key + 16) * kHeadDim + 32 * i, k1[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load8<T>(vbase + (size_t)key * kHeadDim + 32 * i, v0[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load8<T>(vbase + (size_t)(key + 16) * kHeadDim + 32 * i, v1[i]);
+        const float s0 = score(k0), s1 = score(k1);
         absorb(s0, v0);
         absorb(s1, v1);
     }
-    // tail: the shuffles inside dot16 need every lane of the 16-lane group, and all lanes of a group
-    // share `key`, so a whole group is either in or out
+    // tail: all 4 lanes of a key slot share `key`, so the shuffles inside score() stay among active lanes
     if (key < nkeys) {
-        float k0[8], v0[8];
-        load8<T>(kbase + (size_t)key * d, k0);
-        load8<T>(vbase + (size_t)key * d, v0);
-        const float s0 = dot16(k0);
+        float k0[4][8], v0[4][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load8<T>(kbase + (size_t)key * kHeadDim + 32 * i, k0[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load8<T>(vbase + (size_t)key * kHeadDim + 32 * i, v0[i]);
+        const float s0 = score(k0);
         absorb(s0, v0);
     }
-    // merge the four key groups (lanes differing in bits 4 and 5)
+    // merge the 16 key slots (lane bits 2..5)
 #pragma unroll
-    for (int off = 16; off <= 32; off <<= 1) {
+    for (int off = 4; off <= 32; off <<= 1) {
         const float mo = __shfl_xor(m, off, 64);
         const float lo = __shfl_xor(l, off, 64);
         const float mn = fmaxf(m, mo);
@@ -118,18 +145,23 @@ __global__ __launch_bounds__(256) void k_attention(AttnQ qa, const T* __restrict
         const float b = (mo == -INFINITY) ? 0.f : __expf(mo - mn);
         l = l * a + lo * b;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const float ao = __shfl_xor(acc[t], off, 64);
-            acc[t] = acc[t] * a + ao * b;
-        }
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const float ao = __shfl_xor(acc[i][t], off, 64);
+                acc[i][t] = acc[i][t] * a + ao * b;
+            }
         m = mn;
     }
-    if (kg == 0) {
+    if (ks == 0) {
         const float inv = 1.f / l;
-        float o[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) o[t] = acc[t] * inv;
-        store8<T>(out + (size_t)row * d + col, o);
+        for (int i = 0; i < 4; ++i) {
+            float o[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) o[t] = acc[i][t] * inv;
+            store8<T>(out + (size_t)row * d + col + 32 * i, o);
+        }
     }
 }
 

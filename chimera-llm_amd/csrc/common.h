@@ -142,6 +142,9 @@ struct GemmArgs {
     const float* gate;          // (N,) fp32 or null
     void* out; int ldo;
     const int32_t* out_rows;    // optional row map for `out` (length M) or null
+    // With out_rows: > 0 selects the KV-cache layout [slot][head][position][128] -- a mapped row index
+    // r = slot * out_head_cap + position and column n go to ((slot * N/128 + n/128) * out_head_cap + position) * 128 + n%128
+    int out_head_cap;
     int M, N, K;
     int epilogue;
     int dtype;
@@ -212,10 +215,15 @@ int launch_init_latents(const float* noise, float* lat, int64_t n, float sigma, 
 // q/k/v (rows, d) T: rotate q in place, write rotated k and v into the cache rows given by cache_rows.
 int launch_rope_store(void* q, const void* k, const void* v, void* kc, void* vc, const int32_t* cache_rows,
                       const int32_t* positions, const float* cos_tab, const float* sin_tab, int rows, int d,
-                      int use_rope, int dtype, hipStream_t st);
+                      int cap, int use_rope, int dtype, hipStream_t st);
 int launch_add_pos(float* x, const void* table, const int32_t* positions, int rows, int d, int dtype, hipStream_t st);
-int launch_fill_rows(void* cache, const void* vec, const int32_t* rows_idx, int n_rows, int d, int dtype,
+int launch_fill_rows(void* cache, const void* vec, const int32_t* rows_idx, int n_rows, int d, int cap, int dtype,
                      hipStream_t st);
+// Element offset of column n of mapped row r (= slot * cap + position) in a [slot][head][position][128] cache.
+__host__ __device__ inline size_t kv_cache_offset(int r, int n, int cap, int d) {
+    const int slot = r / cap, pos = r % cap;
+    return (((size_t)slot * (d >> 7) + (n >> 7)) * cap + pos) * 128 + (n & 127);
+}
 int launch_silu_cast(const float* x, void* y, int64_t n, int dtype, hipStream_t st);
 int launch_cast(const float* x, void* y, int64_t n, int dtype, hipStream_t st);
 int launch_broadcast_rows(const float* src, float* dst, int rows, int d, hipStream_t st);

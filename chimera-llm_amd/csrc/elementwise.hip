@@ -109,13 +109,13 @@ int launch_denormalize_f32_out(const float* x0, const void* center, const void* 
 // Layer / RMS norm + adaLN modulation.  One workgroup (256 lanes) per row; the row stays in
 // registers between the statistics pass and the output pass (dim <= 8192).
 // ------------------------------------------------------------------------------------------------
-template <typename T, int KIND>
-__global__ __launch_bounds__(256) void k_norm_modulate(float* __restrict__ x, const T* __restrict__ w,
+template <typename T, int KIND, int NT>
+__global__ __launch_bounds__(NT) void k_norm_modulate(float* __restrict__ x, const T* __restrict__ w,
                                                        const T* __restrict__ b, const float* __restrict__ shift,
                                                        const float* __restrict__ scale, T* __restrict__ y, int dim,
                                                        int rows_norm, float eps, Pending pd) {
-    constexpr int MAXV = 8;  // float4 chunks per lane
-    __shared__ float red[4];
+    constexpr int MAXV = 2048 / NT;  // float4 chunks per lane (dim <= 8192)
+    __shared__ float red[NT / 64];
     const int row = blockIdx.x;
     float* xr = x + (size_t)row * dim;
     const int nv = dim / 4;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void k_norm_modulate(float* __restrict__ x, co
     const int src_row = row < pd.M ? row : (pd.dup ? row - pd.M : -1);
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        const int c = threadIdx.x + i * 256;
+        const int c = threadIdx.x + i * NT;
         if (c < nv) {
             if (has_pending && pd.init) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             else v[i] = *reinterpret_cast<const float4*>(xr + c * 4);
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void k_norm_modulate(float* __restrict__ x, co
     float pw[MAXV][4], pb[MAXV][4], psc[MAXV][4], psh[MAXV][4];
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        const int c = threadIdx.x + i * 256;
+        const int c = threadIdx.x + i * NT;
         if (c < nv) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void k_norm_modulate(float* __restrict__ x, co
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        const int c = threadIdx.x + i * 256;
+        const int c = threadIdx.x + i * NT;
         if (c < nv) {
             if (KIND == LCMHIP_NORM_RMS)
                 s += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void k_norm_modulate(float* __restrict__ x, co
                 s += v[i].x + v[i].y + v[i].z + v[i].w;
         }
     }
-    s = block_sum<4>(s, red);
+    s = block_sum<NT / 64>(s, red);
     float mean = 0.f, rstd;
     if (KIND == LCMHIP_NORM_RMS) {
         rstd = rsqrtf(s / dim + eps);
@@ -198,19 +198,19 @@ __global__ __launch_bounds__(256) void k_norm_modulate(float* __restrict__ x, co
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
-            const int c = threadIdx.x + i * 256;
+            const int c = threadIdx.x + i * NT;
             if (c < nv) {
                 const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
                 q += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
             }
         }
-        q = block_sum<4>(q, red);
+        q = block_sum<NT / 64>(q, red);
         rstd = rsqrtf(q / dim + eps);
     }
     T* yr = y + (size_t)row * dim;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        const int c = threadIdx.x + i * 256;
+        const int c = threadIdx.x + i * NT;
         if (c < nv) {
             const int col = c * 4;
             float o[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
@@ -248,13 +248,18 @@ int launch_norm_modulate(float* x, const void* w, const void* b, const float* sh
     }
     const int rows = pend ? rows_total : rows_norm;
     if (rows <= 0) return LCMHIP_OK;
+    // wide rows: 512 lanes per row keep twice as many loads in flight per CU
 #define LCM_NORM(T, KIND)                                                                                      \
-    hipLaunchKernelGGL((k_norm_modulate<T, KIND>), dim3(rows), dim3(256), 0, st, x, (const T*)w, (const T*)b, shift, \
-                       scale, (T*)y, dim, rows_norm, eps, pd)
+    if (dim >= 2048)                                                                                           \
+        hipLaunchKernelGGL((k_norm_modulate<T, KIND, 512>), dim3(rows), dim3(512), 0, st, x, (const T*)w,      \
+                           (const T*)b, shift, scale, (T*)y, dim, rows_norm, eps, pd);                         \
+    else                                                                                                       \
+        hipLaunchKernelGGL((k_norm_modulate<T, KIND, 256>), dim3(rows), dim3(256), 0, st, x, (const T*)w,      \
+                           (const T*)b, shift, scale, (T*)y, dim, rows_norm, eps, pd)
     if (dtype == LCMHIP_BF16) {
-        if (norm_kind == LCMHIP_NORM_RMS) LCM_NORM(bf16_t, LCMHIP_NORM_RMS); else LCM_NORM(bf16_t, LCMHIP_NORM_LAYERNORM);
+        if (norm_kind == LCMHIP_NORM_RMS) { LCM_NORM(bf16_t, LCMHIP_NORM_RMS); } else { LCM_NORM(bf16_t, LCMHIP_NORM_LAYERNORM); }
     } else if (dtype == LCMHIP_F32) {
-        if (norm_kind == LCMHIP_NORM_RMS) LCM_NORM(float, LCMHIP_NORM_RMS); else LCM_NORM(float, LCMHIP_NORM_LAYERNORM);
+        if (norm_kind == LCMHIP_NORM_RMS) { LCM_NORM(float, LCMHIP_NORM_RMS); } else { LCM_NORM(float, LCMHIP_NORM_LAYERNORM); }
     } else {
         return fail(LCMHIP_ERR_INVALID, "norm: unknown dtype");
     }
@@ -417,10 +422,10 @@ __global__ __launch_bounds__(256) void k_rope_store(T* __restrict__ q, const T* 
                                                     const int32_t* __restrict__ cache_rows,
                                                     const int32_t* __restrict__ positions,
                                                     const float* __restrict__ cos_tab,
-                                                    const float* __restrict__ sin_tab, int d, int use_rope) {
+                                                    const float* __restrict__ sin_tab, int d, int cap, int use_rope) {
     const int r = blockIdx.x;
     const size_t src = (size_t)r * d;
-    const size_t dst = (size_t)cache_rows[r] * d;
+    const int crow = cache_rows[r];
     const int pos = positions[r];
     for (int c = threadIdx.x * 8; c < d; c += blockDim.x * 8) {
         float qv[8], kv[8], vv[8];
@@ -440,23 +445,24 @@ __global__ __launch_bounds__(256) void k_rope_store(T* __restrict__ q, const T* 
             }
             store8<T>(q + src + c, qv);
         }
-        store8<T>(kc + dst + c, kv);
-        store8<T>(vc + dst + c, vv);
+        const size_t dst = kv_cache_offset(crow, c, cap, d);   // 8 consecutive dims never straddle a head
+        store8<T>(kc + dst, kv);
+        store8<T>(vc + dst, vv);
     }
 }
 
 int launch_rope_store(void* q, const void* k, const void* v, void* kc, void* vc, const int32_t* cache_rows,
                       const int32_t* positions, const float* cos_tab, const float* sin_tab, int rows, int d,
-                      int use_rope, int dtype, hipStream_t st) {
+                      int cap, int use_rope, int dtype, hipStream_t st) {
     LCM_REQUIRE(d % 128 == 0, "rope: model dim must be a multiple of the 128-wide head");
     if (rows <= 0) return LCMHIP_OK;
     if (dtype == LCMHIP_BF16)
         hipLaunchKernelGGL((k_rope_store<bf16_t>), dim3(rows), dim3(256), 0, st, (bf16_t*)q, (const bf16_t*)k,
-                           (const bf16_t*)v, (bf16_t*)kc, (bf16_t*)vc, cache_rows, positions, cos_tab, sin_tab, d,
+                           (const bf16_t*)v, (bf16_t*)kc, (bf16_t*)vc, cache_rows, positions, cos_tab, sin_tab, d, cap,
                            use_rope);
     else
         hipLaunchKernelGGL((k_rope_store<float>), dim3(rows), dim3(256), 0, st, (float*)q, (const float*)k,
-                           (const float*)v, (float*)kc, (float*)vc, cache_rows, positions, cos_tab, sin_tab, d,
+                           (const float*)v, (float*)kc, (float*)vc, cache_rows, positions, cos_tab, sin_tab, d, cap,
                            use_rope);
     LCM_HIP_CHECK(hipGetLastError());
     return LCMHIP_OK;
@@ -491,25 +497,25 @@ int launch_add_pos(float* x, const void* table, const int32_t* positions, int ro
 // cache[rows_idx[i]][:] = vec[:]   (vec null: zeros)
 template <typename T>
 __global__ __launch_bounds__(256) void k_fill_rows(T* __restrict__ cache, const T* __restrict__ vec,
-                                                   const int32_t* __restrict__ rows_idx, int d) {
-    T* dst = cache + (size_t)rows_idx[blockIdx.x] * d;
+                                                   const int32_t* __restrict__ rows_idx, int d, int cap) {
+    const int crow = rows_idx[blockIdx.x];
     for (int c = threadIdx.x * 8; c < d; c += blockDim.x * 8) {
         float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (vec != nullptr) load8<T>(vec + c, a);
-        store8<T>(dst + c, a);
+        store8<T>(cache + kv_cache_offset(crow, c, cap, d), a);
     }
 }
 
-int launch_fill_rows(void* cache, const void* vec, const int32_t* rows_idx, int n_rows, int d, int dtype,
+int launch_fill_rows(void* cache, const void* vec, const int32_t* rows_idx, int n_rows, int d, int cap, int dtype,
                      hipStream_t st) {
-    LCM_REQUIRE(d % 8 == 0, "fill: dim must be a multiple of 8");
+    LCM_REQUIRE(d % 128 == 0, "fill: dim must be a multiple of the 128-wide head");
     if (n_rows <= 0) return LCMHIP_OK;
     if (dtype == LCMHIP_BF16)
         hipLaunchKernelGGL((k_fill_rows<bf16_t>), dim3(n_rows), dim3(256), 0, st, (bf16_t*)cache, (const bf16_t*)vec,
-                           rows_idx, d);
+                           rows_idx, d, cap);
     else
         hipLaunchKernelGGL((k_fill_rows<float>), dim3(n_rows), dim3(256), 0, st, (float*)cache, (const float*)vec,
-                           rows_idx, d);
+                           rows_idx, d, cap);
     LCM_HIP_CHECK(hipGetLastError());
     return LCMHIP_OK;
 }

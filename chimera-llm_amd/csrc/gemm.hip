@@ -234,15 +234,17 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs p) {
                             v[r] = in * (g / (1.f + __expf(-g)));
                         }
                     }
-                    const size_t orow = p.out_rows ? (size_t)p.out_rows[m] : (size_t)m;
+                    size_t oidx;
+                    if (p.out_rows == nullptr) oidx = (size_t)m * p.ldo + n;
+                    else if (p.out_head_cap > 0) oidx = kv_cache_offset(p.out_rows[m], n, p.out_head_cap, p.N);
+                    else oidx = (size_t)p.out_rows[m] * p.ldo + n;
                     if constexpr (EPI == LCMHIP_EPI_STORE_F32 || sizeof(T) == 4) {
-                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + orow * p.ldo + n) =
-                            make_float4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + oidx) = make_float4(v[0], v[1], v[2], v[3]);
                     } else {
                         uint2 o;
                         o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
                         o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-                        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + orow * p.ldo + n) = o;
+                        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + oidx) = o;
                     }
                 }
             }
@@ -286,15 +288,17 @@ __global__ __launch_bounds__(256) void k_splitk_finish(GemmArgs p, int splits) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             }
-            const size_t orow = p.out_rows ? (size_t)p.out_rows[m] : (size_t)m;
+            size_t oidx;
+            if (p.out_rows == nullptr) oidx = (size_t)m * p.ldo + n;
+            else if (p.out_head_cap > 0) oidx = kv_cache_offset(p.out_rows[m], n, p.out_head_cap, p.N);
+            else oidx = (size_t)p.out_rows[m] * p.ldo + n;
             if constexpr (EPI == LCMHIP_EPI_STORE_F32 || sizeof(T) == 4) {
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + orow * p.ldo + n) =
-                    make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + oidx) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
                 uint2 o;
                 o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
                 o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + orow * p.ldo + n) = o;
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + oidx) = o;
             }
         }
     }
@@ -383,6 +387,7 @@ static int check_args(const GemmArgs& a) {
     LCM_REQUIRE(((size_t)a.lda * es) % 16 == 0 && ((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.W % 16) == 0,
                 "gemm: operands must be 16-byte aligned");
     LCM_REQUIRE(a.extra_rows == 0 || (a.epilogue == LCMHIP_EPI_RESID && a.extra_const), "gemm: extra rows need RESID");
+    LCM_REQUIRE(a.out_head_cap == 0 || (a.out_rows != nullptr && a.N % 128 == 0), "gemm: the KV-cache layout needs a row map and 128-wide heads");
     return LCMHIP_OK;
 }
 

@@ -345,10 +345,11 @@ static void gemm_cost(const GemmArgs& a, double out_es, double* bytes, double* f
 // Product with its epilogue applied (split-K through slab_q + a finishing pass when that pays).
 static int gemm(lcmhip_session* s, const char* tag, const void* A, int lda, const Lin& W, const Lin* W2,
                 const float* gate, void* out, int ldo, int M, int epi, hipStream_t st,
-                const int32_t* out_rows = nullptr, int extra_rows = 0, const float* extra_const = nullptr) {
+                const int32_t* out_rows = nullptr, int extra_rows = 0, const float* extra_const = nullptr,
+                int out_head_cap = 0) {
     GemmArgs a = gemm_args(s, A, lda, W, W2, M, epi);
     a.gate = gate;
-    a.out = out; a.ldo = ldo; a.out_rows = out_rows;
+    a.out = out; a.ldo = ldo; a.out_rows = out_rows; a.out_head_cap = out_head_cap;
     a.extra_rows = extra_rows; a.extra_const = extra_const;
     a.partial = s->slab_q; a.partial_bytes = s->slab_bytes;
     double bytes, flops;
@@ -573,9 +574,9 @@ int lcmhip_session_reset(lcmhip_session* s, int32_t n_docs, void* stream) {
     const size_t layer_bytes = (size_t)s->max_batch * (s->cap + 1) * d.model_dim * es;
     for (int l = 0; l < d.denoiser.num_layers; ++l) {
         LCM_TRY(launch_fill_rows(s->cross_k + l * layer_bytes, m->den[l].ca.k.b, s->slot0_rows, n_docs, d.model_dim,
-                                 d.dtype, st));
+                                 s->cap + 1, d.dtype, st));
         LCM_TRY(launch_fill_rows(s->cross_v + l * layer_bytes, m->den[l].ca.v.b, s->slot0_rows, n_docs, d.model_dim,
-                                 d.dtype, st));
+                                 s->cap + 1, d.dtype, st));
     }
     return LCMHIP_OK;
 }
@@ -713,7 +714,7 @@ int lcmhip_context_append(lcmhip_session* s, const float* x, int32_t n_tokens, i
             {
                 ProfScope ps(&s->prof, "ctx.rope_store", 5.0 * R * dm * es, 0.0, st);
                 LCM_TRY(launch_rope_store(s->act_q, s->act_k, s->act_v, s->self_k + l * self_layer, s->self_v + l * self_layer,
-                                          s->self_rows, s->pos_rows, s->rope_cos, s->rope_sin, R, dm,
+                                          s->self_rows, s->pos_rows, s->rope_cos, s->rope_sin, R, dm, s->cap,
                                           tc.pos_kind == LCMHIP_POS_ROPE, d.dtype, st));
             }
             {
@@ -730,9 +731,9 @@ int lcmhip_context_append(lcmhip_session* s, const float* x, int32_t n_tokens, i
         // cross-attention keys / values of the new context positions, every denoiser layer
         for (int l = 0; l < d.denoiser.num_layers; ++l) {
             LCM_TRY(gemm(s, "ctx.cross_kv", s->act_a, dm, m->den[l].ca.k, nullptr, nullptr, s->cross_k + l * cross_layer, dm, R,
-                         LCMHIP_EPI_STORE, st, s->cross_rows));
+                         LCMHIP_EPI_STORE, st, s->cross_rows, 0, nullptr, s->cap + 1));
             LCM_TRY(gemm(s, "ctx.cross_kv", s->act_a, dm, m->den[l].ca.v, nullptr, nullptr, s->cross_v + l * cross_layer, dm, R,
-                         LCMHIP_EPI_STORE, st, s->cross_rows));
+                         LCMHIP_EPI_STORE, st, s->cross_rows, 0, nullptr, s->cap + 1));
         }
         if (s->keep_context) {
             if (d.dtype == LCMHIP_BF16)

@@ -250,7 +250,8 @@ int lcmhip_ddim_cfg_step(const float* sample, const float* out_cond, const float
 
 /* Single-query-block attention over a per-document key/value cache: fairseq2 TorchSDPA as
  * called at attention.py:272-279 (scale 1/sqrt(128), -inf on masked keys).
- * q: (n_docs * s, H * 128) in `dtype`; k_cache / v_cache: (n_slots, cap, H * 128);
+ * q: (n_docs * s, H * 128) in `dtype`; k_cache / v_cache: (n_slots, H, cap, 128) -- the keys of one
+ * (document, head) are contiguous;
  * slot_map: (n_docs,) int32 or NULL (identity); query j of a document sees keys
  * [0, base_keys + (causal ? j + 1 : 0)).  out: like q. */
 int lcmhip_attention(const void* q, const void* k_cache, const void* v_cache, const int32_t* slot_map,

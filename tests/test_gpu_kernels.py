@@ -192,8 +192,8 @@ def test_attention(hip, dtype, causal, s, base):
     torch.manual_seed(5)
     n_docs, H, cap = 3, 8, 160
     d = H * 128
-    kc = torch.randn(4, cap, d).cuda().to(dtype)       # 4 slots, documents mapped to slots 2, 0, 3
-    vc = torch.randn(4, cap, d).cuda().to(dtype)
+    kc = torch.randn(4, H, cap, 128).cuda().to(dtype)  # [slot][head][position][128]; documents -> slots 2, 0, 3
+    vc = torch.randn(4, H, cap, 128).cuda().to(dtype)
     slot = torch.tensor([2, 0, 3], dtype=torch.int32).cuda()
     q = (2 * torch.randn(n_docs * s, d)).cuda().to(dtype)
     out = torch.empty_like(q)
@@ -201,8 +201,8 @@ def test_attention(hip, dtype, causal, s, base):
                                        base, causal, hip.dtype_code(dtype), _st(hip)))
     nk = base + (s if causal else 0)
     qh = q.float().cpu().view(n_docs, s, H, 128).transpose(1, 2)
-    kh = kc.float().cpu()[[2, 0, 3], :nk].view(n_docs, nk, H, 128).transpose(1, 2)
-    vh = vc.float().cpu()[[2, 0, 3], :nk].view(n_docs, nk, H, 128).transpose(1, 2)
+    kh = kc.float().cpu()[[2, 0, 3], :, :nk]
+    vh = vc.float().cpu()[[2, 0, 3], :, :nk]
     mask = None
     if causal and s > 1:
         mask = torch.full((nk, nk), float("-inf")).triu(1)[nk - s:]
