@@ -50,9 +50,12 @@ def _cosine_betas(n: int, max_beta: float = 0.999) -> Tensor:
 
 def _sigmoid_betas(n: int, alpha: float, beta: float, max_beta: float = 0.999) -> Tensor:
     def bar(t: float) -> float:
-        t = min(max(t, 1e-32), 1 - 1e-32)
-        t = float(torch.tensor(t))  # fp32 clamp like the reference's torch.clamp(torch.tensor(t))
-        return 1 / (1 + math.exp(-(beta - alpha * math.log(t / (1 - t)))))
+        # the clamp and the odds run in fp32 (the reference clamps a torch scalar), the rest in Python floats;
+        # t = 1 rounds to odds = inf and alpha_bar = 0
+        x = torch.tensor(t).clamp(min=1e-32, max=1 - 1e-32)
+        odds = float(x / (1 - x))
+        z = beta - alpha * (math.inf if odds == math.inf else math.log(odds))
+        return 0.0 if z == -math.inf else 1 / (1 + math.exp(-z))
 
     return torch.tensor([min(1 - bar((i + 1) / n) / bar(i / n), max_beta) for i in range(n)], dtype=torch.float32)
 

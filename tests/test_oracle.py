@@ -1,0 +1,220 @@
+"""Checks that keep the self-made CPU oracle honest (no GPU needed).
+
+The reference ships no numeric golden vectors for the two-tower generation path and cannot be
+imported here, so the oracle is pinned by: constants the reference's own files state
+(parameter counts, timestep lists), table anchors, two independent statements of RoPE / SDPA,
+the reference's *invariant* tests restated for this path (KV cache on/off, batched vs single,
+determinism -- tests/units/inference/test_base_lcm_kv_caching.py:17-74,
+test_base_lcm_batched_inference.py:21-155, tests/units/models/test_lcm_architecture.py:78-112)
+and analytic identities of the algorithm.
+"""
+
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle
+from oracle.archs import SchedulerConfig
+from oracle.model import KVCache, causal_mask, rope, rope_explicit, sdpa
+from oracle.weights import num_parameters, synthetic_noise, synthetic_prompts
+
+OPTS = dict(guidance_scale=3.0, guidance_rescale=0.7, initial_noise_scale=0.6, eos_threshold=None)
+
+
+def _model(arch, seed=0, **kw):
+    cfg = oracle.get_arch(arch)
+    init = dict(mod_gain=10.0, qk_gain=2.0)
+    init.update(kw)
+    return cfg, oracle.OracleTwoTower(cfg, oracle.init_state_dict(cfg, seed=seed, **init))
+
+
+# ----------------------------------------------------------------------------- constants of the reference
+def test_parameter_counts_match_reference_docstrings():
+    # lcm/models/two_tower_diffusion_lcm/archs.py:73-74 states 6,930,781,696 for the 7B arch: the
+    # state-dict shapes (GLU rounding to 5632 / 11008, biases, modulators) reproduce it exactly.
+    assert num_parameters(oracle.get_arch("two_tower_diffusion_lcm_7B")) == 6_930_781_696
+    # The 1.6B docstring (archs.py:29-30: 1,635,101,696) differs from the count its own config gives.
+    assert num_parameters(oracle.get_arch("two_tower_diffusion_lcm_1_6B")) == 1_645_538_304
+    from oracle.archs import glu_inner_dim
+    assert glu_inner_dim(8192) == 5632 and glu_inner_dim(4096) == 2816 and glu_inner_dim(16384) == 11008
+
+
+def test_timestep_lists():
+    # lcm/nn/schedulers/ddim.py:333-347: the integer arange truncates the step (T=100, S=40 -> 50 steps)
+    s = oracle.DDIMSchedule(SchedulerConfig(num_train_steps=100))
+    s.set_timesteps(40)
+    assert s.timesteps.tolist() == list(range(99, 0, -2))
+    s.set_timesteps(100)
+    assert s.timesteps.tolist() == list(range(99, -1, -1))
+    s = oracle.DDIMSchedule(SchedulerConfig(num_train_steps=1000))
+    s.set_timesteps(10)
+    assert s.timesteps.tolist() == [999, 899, 799, 699, 599, 499, 399, 299, 199, 99]   # ddim.py:335 comment
+    with pytest.raises(ValueError):
+        s.set_timesteps(1001)
+
+
+def test_alpha_table_anchors():
+    s100 = oracle.DDIMSchedule(SchedulerConfig(num_train_steps=100))
+    ac = s100.alphas_cumprod
+    assert abs(float(ac[0]) - 0.99936867) < 1e-6 and abs(float(ac[50]) - 0.47805437) < 1e-6
+    assert abs(float(ac[98]) - 2.2796521e-4) < 1e-8 and float(ac[99]) == 0.0       # zero terminal SNR
+    s1000 = oracle.DDIMSchedule(SchedulerConfig(num_train_steps=1000))
+    assert abs(float(s1000.alphas_cumprod[500]) - 0.49226481) < 1e-6 and float(s1000.alphas_cumprod[999]) == 0.0
+    assert torch.all(ac[1:] <= ac[:-1])
+
+
+# ----------------------------------------------------------------------------- primitives, stated twice
+def test_rope_two_statements_agree():
+    x = torch.randn(2, 3, 5, 128)
+    # the complex form rounds the angle to fp32 (like fairseq2); the explicit form uses double angles, so the
+    # tolerance grows with the position (angle error ~ pos * 6e-8 rad)
+    for start, tol in ((0, 2e-5), (7, 2e-5), (1000, 5e-4)):
+        assert torch.allclose(rope(x, start, 10000.0), rope_explicit(x, start, 10000.0), atol=tol)
+    assert torch.allclose(rope(x, 0, 10000.0)[..., 0, :], x[..., 0, :], atol=1e-6)      # position 0 is the identity
+    # rotating pairs preserves the norm of every pair
+    y = rope(x, 13, 10000.0)
+    assert torch.allclose(y.unflatten(-1, (-1, 2)).norm(dim=-1), x.unflatten(-1, (-1, 2)).norm(dim=-1), atol=1e-5)
+
+
+def test_sdpa_matches_torch():
+    q, k, v = torch.randn(3, 4, 5, 128), torch.randn(3, 4, 9, 128), torch.randn(3, 4, 9, 128)
+    assert torch.allclose(sdpa(q, k, v, None, None), F.scaled_dot_product_attention(q, k, v), atol=1e-5)
+    lens = torch.tensor([9, 4, 1])
+    keep = (torch.arange(9)[None] < lens[:, None])[:, None, None, :]
+    assert torch.allclose(sdpa(q, k, v, lens, None), F.scaled_dot_product_attention(q, k, v, attn_mask=keep), atol=1e-5)
+    m = causal_mask(5, 9)
+    ref = F.scaled_dot_product_attention(q, k, v, attn_mask=(m == 0))
+    assert torch.allclose(sdpa(q, k, v, None, m), ref, atol=1e-5)
+    assert causal_mask(1, 9) is None and causal_mask(4, 4).shape == (4, 4)
+
+
+# ----------------------------------------------------------------------------- invariants of the reference tests
+@pytest.mark.parametrize("arch", ["toy_two_tower_diffusion_lcm", "mini_two_tower_diffusion_lcm"])
+@pytest.mark.parametrize("prefix", [1, 2, 8])
+def test_kv_cache_equals_full_encode(arch, prefix):
+    cfg, m = _model(arch)
+    x = torch.randn(2, prefix + 3, 1024)
+    full = m.encode(x)
+    cache = KVCache(32)
+    parts = [m.encode(x[:, :prefix], cache)]
+    cache.increment_step_nr(prefix)
+    for t in range(prefix, prefix + 3):
+        parts.append(m.encode(x[:, t:t + 1], cache))
+        cache.increment_step_nr(1)
+    assert torch.allclose(torch.cat(parts, 1), full, atol=1e-3)        # tolerance of the reference test
+
+
+@pytest.mark.parametrize("arch", ["toy_two_tower_diffusion_lcm", "mini_two_tower_diffusion_lcm"])
+def test_batched_equals_single_and_is_deterministic(arch):
+    cfg, m = _model(arch)
+    norm = oracle.load_dummy_normalizer()
+    lens = [2, 4, 3]
+    x = synthetic_prompts(norm, 3, 4)
+    for i, n in enumerate(lens):
+        x[i, n:] = 0
+    nz = synthetic_noise(8, 3)
+    gen = oracle.OracleGenerator(m, oracle.GenOptions(**OPTS, inference_timesteps=5))
+    out = gen(x, prompt_lens=torch.tensor(lens), max_gen_len=3, noise=nz)
+    again = gen(x, prompt_lens=torch.tensor(lens), max_gen_len=3, noise=nz)
+    for i, n in enumerate(lens):
+        assert out[i][0].seq.shape[0] == n + 3                       # never stops before max_gen_len
+        assert torch.equal(out[i][0].seq, again[i][0].seq)
+        # noise is consumed as noise[step - min_prompt_len, doc]: a single document starts later
+        single = gen(x[i:i + 1, :n], max_gen_len=3, noise=nz[n - min(lens):, i:i + 1])
+        assert torch.allclose(single[0][0].seq, out[i][0].seq, atol=1e-5), i
+
+
+def test_guidance_scale_one_plus_eps_approaches_unguided_path():
+    cfg, m = _model("mini_two_tower_diffusion_lcm")
+    x, nz = synthetic_prompts(oracle.load_dummy_normalizer(), 2, 3), synthetic_noise(2, 2)
+    base = dict(OPTS, inference_timesteps=10, guidance_rescale=0.0)
+    plain = oracle.OracleGenerator(m, oracle.GenOptions(**dict(base, guidance_scale=1.0)))(x, max_gen_len=2, noise=nz)
+    cfgd = oracle.OracleGenerator(m, oracle.GenOptions(**dict(base, guidance_scale=1.0 + 1e-6)))(x, max_gen_len=2, noise=nz)
+    c, s = m.sd["sonar_normalizer.center"], m.sd["sonar_normalizer.scale"]
+    for a, b in zip(plain, cfgd):
+        assert torch.allclose((a[0].seq - c) / s, (b[0].seq - c) / s, atol=2e-3)
+
+
+# ----------------------------------------------------------------------------- analytic identities
+def test_zero_modulators_make_denoiser_layers_identity():
+    cfg = oracle.get_arch("mini_two_tower_diffusion_lcm")
+    sd = oracle.init_state_dict(cfg, seed=3, mod_gain=0.0)           # the reference's zero-init (lcm_denoiser.py:55-58)
+    m = oracle.OracleTwoTower(cfg, sd)
+    lat, ctx = torch.randn(2, 1, 1024), torch.randn(2, 4, cfg.model_dim)
+    out = m.denoise(lat, torch.full((2, 1), 50), ctx)
+    from oracle.model import linear, norm
+    ref = linear(norm(linear(lat, sd, "denoiser.initial_proj.fc"), sd, "denoiser.layer_norm", "rms", cfg.norm_eps), sd,
+                 "denoiser.final_proj.fc")
+    assert torch.allclose(out, ref, atol=1e-5)
+
+
+def test_unconditional_cross_attention_is_a_constant():
+    """Rows with context length 0 only see the prepended zero vector: output_proj(v_proj(0)) = W_o b_v + b_o,
+    whatever the (masked) context holds."""
+    cfg, m = _model("mini_two_tower_diffusion_lcm")
+    lat = torch.randn(2, 1, 1024)
+    ts = torch.full((2, 1), 30)
+    a = m.denoise(lat, ts, torch.randn(2, 5, cfg.model_dim), torch.zeros(2, dtype=torch.long))
+    b = m.denoise(lat, ts, torch.randn(2, 5, cfg.model_dim), torch.zeros(2, dtype=torch.long))
+    assert torch.allclose(a, b, atol=1e-6)
+    sd, p = m.sd, "denoiser.layers.0.cross_attention"
+    h = torch.randn(1, 1, cfg.model_dim)
+    got = m._mha(p, cfg.denoiser, h, torch.zeros(1, 1, cfg.model_dim), key_lens=torch.tensor([1]))
+    want = sd[p + ".output_proj.weight"] @ sd[p + ".v_proj.bias"] + sd[p + ".output_proj.bias"]
+    assert torch.allclose(got.flatten(), want, atol=1e-5)
+
+
+def test_ddim_end_points():
+    s = oracle.DDIMSchedule(SchedulerConfig(num_train_steps=100))
+    s.set_timesteps(40)
+    x, out = torch.randn(3, 1, 1024), torch.randn(3, 1, 1024)
+    # first step, alpha_bar = 0: "sample" prediction gives x0 = model output and eps = x_t
+    prev, x0 = s.step(out, 99, x)
+    assert torch.equal(x0, out)
+    a_prev = s.alphas_cumprod[97]
+    assert torch.allclose(prev, a_prev**0.5 * out + (1 - a_prev) ** 0.5 * x, atol=1e-6)
+    # last step: previous alpha_bar = 1 -> prev_sample == pred_original_sample
+    prev, x0 = s.step(out, 1, x)
+    assert torch.allclose(prev, x0, atol=1e-6)
+    # get_epsilon inverts the "sample" parameterisation
+    eps = s.get_epsilon(out, x, 57)
+    a = s.alphas_cumprod[57]
+    assert torch.allclose(a**0.5 * out + (1 - a) ** 0.5 * eps, x, atol=1e-5)
+
+
+def test_cfg_rescale_properties():
+    class M:
+        guidance_scale, guidance_rescale = 3.0, 1.0
+    eps = torch.randn(8, 1, 1024)
+    g = oracle.OracleTwoTower.apply_cfg(M, eps)
+    # full rescale: the guided noise has the std of the conditional prediction
+    assert torch.allclose(g.std(-1), eps.chunk(2)[0].std(-1), rtol=1e-5)
+    M.guidance_rescale, M.guidance_scale = 0.0, 1.0
+    assert torch.allclose(oracle.OracleTwoTower.apply_cfg(M, eps), eps.chunk(2)[0], atol=1e-6)
+
+
+# ----------------------------------------------------------------------------- regression fixture
+def test_golden_fixture_regression():
+    blob = torch.load(os.path.join(os.path.dirname(__file__), "golden", "toy_two_tower_golden.pt"), weights_only=True)
+    cfg = oracle.get_arch(blob["arch"])
+    sd = oracle.init_state_dict(cfg, **blob["init"])
+    trace = []
+    gen = oracle.OracleGenerator(oracle.OracleTwoTower(cfg, sd), oracle.GenOptions(**blob["options"]))
+    hyps = gen(blob["prompts"], max_gen_len=blob["G"], noise=blob["noise"], trace=trace)
+    assert torch.equal(gen.model.scheduler.timesteps, blob["timesteps"])
+    out = torch.stack([h[0].seq for h in hyps])
+    scale = sd["sonar_normalizer.scale"]
+    assert ((out - blob["outputs"]) / scale).abs().max() <= 1e-4          # normalizer units
+    assert (trace[0][1] - blob["latents_step0"]).abs().max() <= 1e-5
+    assert (trace[len(blob["timesteps"]) - 1][2] - blob["x0_last"]).abs().max() <= 1e-4
+
+
+def test_dummy_normalizer_fixture():
+    n = oracle.load_dummy_normalizer()
+    assert n["center"].shape == (1024,) and n["scale"].shape == (1024,) and n["center"].dtype == torch.float32
+    assert float(n["scale"].min()) > 0
+    x = torch.randn(4, 1024)
+    cfg, m = _model("toy_two_tower_diffusion_lcm")
+    assert torch.allclose(m.denormalize(m.normalize(x)), x, atol=1e-5)
