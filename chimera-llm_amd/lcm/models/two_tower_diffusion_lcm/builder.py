@@ -152,7 +152,7 @@ class DeviceSession:
 
     def __del__(self) -> None:
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and _hip is not None and getattr(_hip, "lib", None) is not None:   # None during interpreter shutdown
             _hip.lib.lcmhip_session_destroy(h)
 
     def _stream(self):
@@ -371,7 +371,7 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
         if pool:
             pool.clear()
         h, self._handle = getattr(self, "_handle", None), None
-        if h:
+        if h and _hip is not None and getattr(_hip, "lib", None) is not None:
             _hip.lib.lcmhip_model_destroy(h)
 
     # ---- generation set-up ------------------------------------------------------------------------------

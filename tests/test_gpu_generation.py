@@ -8,6 +8,7 @@ the model works in) and per-embedding cosine >= 0.9999; bf16 -- cosine >= 0.999.
 import pytest
 import torch
 
+from lcm.inference.two_tower_diffusion_lcm import DiffusionLCMGeneratorOptions
 from parity_utils import DEFAULT_OPTS, compare, make_problem, run_hip, run_oracle
 
 pytestmark = pytest.mark.gpu
@@ -118,33 +119,55 @@ def test_toy_fp32_against_golden_fixture():
     assert diff <= FP32_MAX_ABS, float(diff)
     # per-step latents of the first generated sentence through predict_next_sentence(trace=...)
     from lcm.datasets.batch import EmbeddingsBatch
-    P = blob["P"]
-    ctx = model.encode(EmbeddingsBatch(blob["prompts"].cuda()), normalized=False)
-    trace = []
-    opts = blob["options"]
-    model.predict_next_sentence(
-        ctx, noise=blob["noise"][0].cuda(), trace=trace, inference_timesteps=opts["inference_timesteps"],
-        guidance_scale=opts["guidance_scale"], guidance_rescale=opts["guidance_rescale"],
-        initial_noise_scale=opts["initial_noise_scale"])
-    lat = trace[0].float().cpu()      # (steps, B, 1024)
+    from lcm.nn.incremental_state import LCMIncrementalStateBag
+    P, B, opts = blob["P"], blob["B"], blob["options"]
+    model.prep_for_denoising(DiffusionLCMGeneratorOptions(**opts))
+    bag = LCMIncrementalStateBag(P + 1)
+    x = blob["prompts"].cuda()
+    ctx = model.encode(EmbeddingsBatch(x[:, :P - 1]), bag, normalized=False)
+    bag.increment_step_nr(P - 1)
+    steps = len(model.noise_scheduler.timesteps)
+    trace = torch.zeros(steps, B, 1024, device="cuda:0")
+    model.predict_next_sentence(EmbeddingsBatch(x[:, P - 1:P]), ctx, context_state_bag=bag, noise=blob["noise"][0].cuda(),
+                                trace=trace)
+    lat = trace.cpu()
     for idx, key in [(0, "latents_step0"), (1, "latents_step1"), (-1, "latents_last")]:
         want = blob[key].reshape(lat[idx].shape)
         assert (lat[idx] - want).abs().max() <= FP32_MAX_ABS, key
-    model.release_session()
 
 
 @pytest.mark.timeout(900)
 def test_1_6b_bf16_reduced_batch():
     """BASELINE config 3's architecture (1.6B, bf16, 40 requested -> 50 executed steps, CFG 3.0 / 0.7) at
-    a batch the fp32 CPU oracle finishes in about a minute: 4 docs x (3 prompt + 2 generated)."""
+    a batch the fp32 CPU oracle finishes in about a minute: 4 docs x (3 prompt + 2 generated).
+
+    The random weights use milder gains than the small-model tests (modulator x4, q/k x1): with the x10 / x2
+    gains a 13-layer random denoiser amplifies bf16 rounding of the activations to cosine 0.9990 after one
+    sentence and 0.985 after two (fp32 on the same weights stays within 6e-5 of the oracle), which measures
+    the conditioning of that random network rather than the kernels."""
     arch = "two_tower_diffusion_lcm_1_6B"
-    cfg, sd, x, nz = make_problem(arch, 4, 3, 2)
+    cfg, sd, x, nz = make_problem(arch, 4, 3, 2, mod_gain=4.0, qk_gain=1.0)
     opts = dict(DEFAULT_OPTS, inference_timesteps=40)
     sd = {k: v.bfloat16().float() for k, v in sd.items()}
     ref = run_oracle(cfg, sd, x.bfloat16().float(), nz, 2, opts)
-    out, _ = run_hip(arch, sd, x, nz, 2, opts, dtype=torch.bfloat16)
+    out, model = run_hip(arch, sd, x, nz, 2, opts, dtype=torch.bfloat16)
     worst, cos = compare(out.hypotheses, ref, sd, start=3)
     assert cos >= BF16_COS, (worst, cos)
+    del model, out
+
+
+@pytest.mark.timeout(900)
+def test_1_6b_fp32_reduced_batch():
+    """Same architecture in fp32 with the strong gains: the kernels themselves track the oracle to the
+    fp32 bar through 13 layers x 50 steps x 2 sentences."""
+    arch = "two_tower_diffusion_lcm_1_6B"
+    cfg, sd, x, nz = make_problem(arch, 3, 3, 2)
+    opts = dict(DEFAULT_OPTS, inference_timesteps=40)
+    ref = run_oracle(cfg, sd, x, nz, 2, opts)
+    out, model = run_hip(arch, sd, x, nz, 2, opts)
+    worst, cos = compare(out.hypotheses, ref, sd, start=3)
+    assert worst <= FP32_MAX_ABS and cos >= FP32_COS, (worst, cos)
+    del model, out
 
 
 @pytest.mark.timeout(900)
