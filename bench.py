@@ -96,7 +96,26 @@ def roofline_pass(model, gen_cls, opt_cls, batch, prompt_len, gen_len, device):
                 frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
                 avg_launch_us=round(1e3 * dom["total_ms"] / dom["launches"], 3),
                 bytes_per_launch=round(dom["bytes"] / dom["launches"]))
+    roof.update(pmc_traffic(dom["name"]))
     return roof, table
+
+
+# kernel family -> the epilogue id in the HIP symbol rocprofv3 reports for it
+_PMC_SYMBOL = {"den.ffn_in": ", 3>(", "den.norm_mod": "k_norm_modulate", "den.cross_attn": "k_attention"}
+
+
+def pmc_traffic(family):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (FETCH_SIZE doubled for gfx950 + WRITE_SIZE; counters cannot be read from inside this process)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_hbm_traffic.json")
+    key = _PMC_SYMBOL.get(family)
+    if key is None or not os.path.exists(path):
+        return {"traffic": None}
+    for row in json.load(open(path))["kernels"]:
+        if key in row["kernel"]:
+            return {"traffic": row["hbm_bytes_per_launch_corrected"],
+                    "traffic_source": "profiles/r1_pmc_hbm_traffic.json (separate rocprofv3 --pmc passes)"}
+    return {"traffic": None}
 
 
 def cpu_baseline(batch, prompt_len, sentence_steps):
