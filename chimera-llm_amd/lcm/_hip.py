@@ -11,7 +11,8 @@ from typing import List, Tuple
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblcm_hip.so")
+# LCMHIP_LIB selects an experimental build of the same ABI (kernel ablation studies); never a fallback
+LIB_PATH = os.environ.get("LCMHIP_LIB") or os.path.join(_HERE, "liblcm_hip.so")
 
 F32, BF16 = 0, 1
 NORM_LAYERNORM, NORM_RMS = 0, 1
