@@ -18,6 +18,42 @@ namespace lcmhip {
 
 constexpr int kHeadDim = 128;
 
+// Eight consecutive elements as loaded (16 bytes of bf16, 32 bytes of f32) and their fp32 values.
+template <typename T>
+struct PieceT;
+template <>
+struct PieceT<bf16_t> { using type = __attribute__((ext_vector_type(4))) uint32_t; };
+template <>
+struct PieceT<float> { using type = __attribute__((ext_vector_type(8))) float; };   // native vectors stay in registers
+template <typename T>
+using Piece = typename PieceT<T>::type;
+
+template <typename T>
+__device__ __forceinline__ Piece<T> load_piece(const T* p);
+template <>
+__device__ __forceinline__ Piece<bf16_t> load_piece<bf16_t>(const bf16_t* p) {
+    return *reinterpret_cast<const Piece<bf16_t>*>(p);
+}
+template <>
+__device__ __forceinline__ Piece<float> load_piece<float>(const float* p) {
+    return *reinterpret_cast<const Piece<float>*>(p);   // 32-byte aligned: pieces start at multiples of 8 floats
+}
+template <typename T>
+__device__ __forceinline__ void unpack8(const Piece<T>& r, float (&v)[8]);
+template <>
+__device__ __forceinline__ void unpack8<bf16_t>(const Piece<bf16_t>& r, float (&v)[8]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v[2 * j] = __uint_as_float(r[j] << 16);
+        v[2 * j + 1] = __uint_as_float(r[j] & 0xffff0000u);
+    }
+}
+template <>
+__device__ __forceinline__ void unpack8<float>(const Piece<float>& r, float (&v)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = r[j];
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_attention(AttnQ qa, const T* __restrict__ kc, const T* __restrict__ vc,
                                                    const int32_t* __restrict__ slot_map, T* __restrict__ out, int s,
@@ -36,12 +72,14 @@ __global__ __launch_bounds__(256) void k_attention(AttnQ qa, const T* __restrict
 
     float qv[4][8];
     if (qa.partial != nullptr) {
+        // split-K slab of the q projection: key slot ks sums splits ks, ks + 16, ... for this lane's 32 dims
+        // (one round of loads for up to 16 splits), then the 16 slots are added with a butterfly, which
+        // leaves the same bits in every slot.
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int t = 0; t < 8; ++t) qv[i][t] = 0.f;
-#pragma unroll 2
-        for (int sp = 0; sp < qa.splits; ++sp) {
+        for (int sp = ks; sp < qa.splits; sp += 16) {
             const float* src = qa.partial + ((size_t)sp * qa.rows + row) * d + col;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -51,7 +89,7 @@ __global__ __launch_bounds__(256) void k_attention(AttnQ qa, const T* __restrict
                 for (int t = 0; t < 8; ++t) qv[i][t] += t8[t];
             }
         }
-        if (qa.bias != nullptr) {
+        if (qa.bias != nullptr && ks == 0) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float b8[8];
@@ -60,6 +98,12 @@ __global__ __launch_bounds__(256) void k_attention(AttnQ qa, const T* __restrict
                 for (int t = 0; t < 8; ++t) qv[i][t] += b8[t];
             }
         }
+#pragma unroll
+        for (int off = 4; off <= 32; off <<= 1)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) qv[i][t] += __shfl_xor(qv[i][t], off, 64);
         // the reference rounds q to the operand dtype before the scores
         if (sizeof(T) == 2) {
 #pragma unroll
@@ -88,52 +132,63 @@ __global__ __launch_bounds__(256) void k_attention(AttnQ qa, const T* __restrict
         for (int t = 0; t < 8; ++t) acc[i][t] = 0.f;
 
     // score of one key: partial dot over this lane's 32 dims, summed over the slot's 4 lanes
-    auto score = [&](const float (&kv)[4][8]) {
+    auto score = [&](const Piece<T> (&kp)[4]) {
         float p = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+            float kv[8];
+            unpack8<T>(kp[i], kv);
 #pragma unroll
-            for (int t = 0; t < 8; ++t) p += kv[i][t] * qv[i][t];
+            for (int t = 0; t < 8; ++t) p += kv[t] * qv[i][t];
+        }
         p += __shfl_xor(p, 1, 64);
         p += __shfl_xor(p, 2, 64);
         return p;
     };
-    auto absorb = [&](float sc, const float (&vv)[4][8]) {
+    auto absorb = [&](float sc, const Piece<T> (&vp)[4]) {
         const float mn = fmaxf(m, sc);
         const float alpha = __expf(m - mn);
         const float p = __expf(sc - mn);
         l = l * alpha + p;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+            float vv[8];
+            unpack8<T>(vp[i], vv);
 #pragma unroll
-            for (int t = 0; t < 8; ++t) acc[i][t] = acc[i][t] * alpha + p * vv[i][t];
+            for (int t = 0; t < 8; ++t) acc[i][t] = acc[i][t] * alpha + p * vv[t];
+        }
         m = mn;
     };
 
+    // U keys per slot and iteration (16 * U keys per wave), kept packed in registers until they are used
+    constexpr int U = sizeof(T) == 2 ? 4 : 2;
     int key = ks;
-    for (; key + 16 < nkeys; key += 32) {
-        float k0[4][8], k1[4][8], v0[4][8], v1[4][8];
+    for (; key + 16 * (U - 1) < nkeys; key += 16 * U) {
+        Piece<T> kp[U][4], vp[U][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) load8<T>(kbase + (size_t)key * kHeadDim + 32 * i, k0[i]);
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) load8<T>(kbase + (size_t)(key + 16) * kHeadDim + 32 * i, k1[i]);
+            for (int i = 0; i < 4; ++i) kp[u][i] = load_piece<T>(kbase + (size_t)(key + 16 * u) * kHeadDim + 32 * i);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) load8<T>(vbase + (size_t)key * kHeadDim + 32 * i, v0[i]);
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) load8<T>(vbase + (size_t)(key + 16) * kHeadDim + 32 * i, v1[i]);
-        const float s0 = score(k0), s1 = score(k1);
-        absorb(s0, v0);
-        absorb(s1, v1);
+            for (int i = 0; i < 4; ++i) vp[u][i] = load_piece<T>(vbase + (size_t)(key + 16 * u) * kHeadDim + 32 * i);
+        float sc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) sc[u] = score(kp[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) absorb(sc[u], vp[u]);
     }
-    // tail: all 4 lanes of a key slot share `key`, so the shuffles inside score() stay among active lanes
-    if (key < nkeys) {
-        float k0[4][8], v0[4][8];
+    // tail: one key per slot and iteration; all 4 lanes of a slot share `key`, so the shuffles inside
+    // score() stay among active lanes
+    for (; key < nkeys; key += 16) {
+        Piece<T> kp[4], vp[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) load8<T>(kbase + (size_t)key * kHeadDim + 32 * i, k0[i]);
+        for (int i = 0; i < 4; ++i) kp[i] = load_piece<T>(kbase + (size_t)key * kHeadDim + 32 * i);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) load8<T>(vbase + (size_t)key * kHeadDim + 32 * i, v0[i]);
-        const float s0 = score(k0);
-        absorb(s0, v0);
+        for (int i = 0; i < 4; ++i) vp[i] = load_piece<T>(vbase + (size_t)key * kHeadDim + 32 * i);
+        const float s0 = score(kp);
+        absorb(s0, vp);
     }
     // merge the 16 key slots (lane bits 2..5)
 #pragma unroll

@@ -54,6 +54,14 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+#ifndef LCM_NT_WEIGHTS
+#define LCM_NT_WEIGHTS 0   // 1: weights (read once per launch) are loaded with the non-temporal policy
+#endif
+#if LCM_NT_WEIGHTS
+#define LCM_WLOAD(p) __builtin_nontemporal_load(p)
+#else
+#define LCM_WLOAD(p) (*(p))
+#endif
 #ifndef LCM_DEPTH2
 #define LCM_DEPTH2 0   // 1: two chunks of loads in flight per workgroup (measured slower: the tile is bound by LDS and L1 intake, not by latency); 0: one
 #endif
@@ -123,9 +131,9 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs p) {
                 /* tile row 8i + r0 belongs to wave (8i) / WR; a wave's first WR/2 rows = gate, rest = inner */ \
                 const int grp = (8 * i) / WR, rr = (8 * i) % WR;                                         \
                 const char* b = (rr < WR / 2 ? w_base : w2_base) + (size_t)(grp * (WR / 2) + (rr % (WR / 2))) * kbytes; \
-                RW[i] = *reinterpret_cast<const u32x4*>(b + off_);                                       \
+                RW[i] = LCM_WLOAD(reinterpret_cast<const u32x4*>(b + off_));                             \
             } else {                                                                                     \
-                RW[i] = *reinterpret_cast<const u32x4*>(w_base + (size_t)(8 * i) * kbytes + off_);       \
+                RW[i] = LCM_WLOAD(reinterpret_cast<const u32x4*>(w_base + (size_t)(8 * i) * kbytes + off_)); \
             }                                                                                            \
         }                                                                                                \
     }
