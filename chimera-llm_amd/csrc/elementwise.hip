@@ -133,7 +133,7 @@ __global__ __launch_bounds__(NT) void k_norm_modulate(float* __restrict__ x, con
                 float4 a;
                 if (src_row >= 0) {
                     a = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
+#pragma unroll 8
                     for (int s = 0; s < pd.splits; ++s) {
                         const float4 t = *reinterpret_cast<const float4*>(pd.partial + ((size_t)s * pd.M + src_row) * dim + c * 4);
                         a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;

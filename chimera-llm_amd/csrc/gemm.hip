@@ -16,12 +16,10 @@
 #include <type_traits>
 
 #include "common.h"
+#include "gemm_epilogue.h"
 
 namespace lcmhip {
 
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;   // native vector: stays in registers (HIP's uint4 is a struct)
 
 template <typename T>
 struct Mma;
@@ -62,6 +60,18 @@ __device__ __forceinline__ void static_for(F&& f) {
 #else
 #define LCM_WLOAD(p) (*(p))
 #endif
+// timing-only address remaps (LCM_ABLATE 4, 5): pretend the operand is stored chunk-major, i.e. the 512-byte
+// pieces of one K chunk of consecutive rows are contiguous (row pitch 512 B, chunk pitch rows * 512 B)
+#if LCM_ABLATE == 4 || LCM_ABLATE == 5
+#define LCM_CM_W(rowptr, base, off) cm_addr(rowptr, reinterpret_cast<const char*>(base), kbytes, (size_t)p.N, off)
+#else
+#define LCM_CM_W(rowptr, base, off) ((rowptr) + (off))
+#endif
+#if LCM_ABLATE == 5
+#define LCM_CM_A(rowptr, off) cm_addr(rowptr, reinterpret_cast<const char*>(p.A), a_stride, (size_t)p.M, off)
+#else
+#define LCM_CM_A(rowptr, off) ((rowptr) + (off))
+#endif
 #ifndef LCM_DEPTH2
 #define LCM_DEPTH2 0   // 1: two chunks of loads in flight per workgroup (measured slower: the tile is bound by LDS and L1 intake, not by latency); 0: one
 #endif
@@ -70,7 +80,6 @@ __device__ __forceinline__ void static_for(F&& f) {
 #endif
 constexpr int kChunkBytes = 512;             // bytes of K per tile row per chunk
 constexpr int kRowBytes = kChunkBytes + 16;  // padded LDS row
-constexpr int EPI_PARTIAL = 100;             // internal: raw fp32 partial tile to the split-K slab
 
 // WM x WN waves; each wave owns 32 activation rows x (16 * TN) weight rows.
 template <typename T, int WM, int WN, int TN, int EPI>
@@ -113,6 +122,12 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs p) {
         w_base = reinterpret_cast<const char*>(p.W) + (size_t)(blockIdx.x * BNR + r0) * kbytes + col_off;
     }
     char* lds_dst = smem + r0 * kRowBytes + (tid & 31) * 16;
+    // timing studies only: address of the same piece if the operand were stored chunk-major
+    auto cm_addr = [&](const char* rowptr, const char* base, size_t pitch, size_t rows, size_t off) {
+        const size_t row = (size_t)(rowptr - base) / pitch;
+        return base + row * 512 + (off / 512 + c_begin) * rows * 512 + (tid & 31) * 16;
+    };
+    (void)cm_addr;
 
     // Two register sets: while one chunk is being consumed from LDS, the loads of the next TWO chunks are
     // in flight (vector-memory loads retire in order, so waiting for the older set leaves the newer
@@ -124,20 +139,20 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs p) {
         _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                 \
             int m = m0 + r0 + 8 * i;                                                                     \
             m = m < p.M ? m : p.M - 1;                                                                   \
-            RA[i] = *reinterpret_cast<const u32x4*>(a_base + (size_t)m * a_stride + off_);               \
+            RA[i] = *reinterpret_cast<const u32x4*>(LCM_CM_A(a_base + (size_t)m * a_stride, off_));      \
         }                                                                                                \
         _Pragma("unroll") for (int i = 0; i < NW; ++i) {                                                 \
             if constexpr (DUAL) {                                                                        \
                 /* tile row 8i + r0 belongs to wave (8i) / WR; a wave's first WR/2 rows = gate, rest = inner */ \
                 const int grp = (8 * i) / WR, rr = (8 * i) % WR;                                         \
                 const char* b = (rr < WR / 2 ? w_base : w2_base) + (size_t)(grp * (WR / 2) + (rr % (WR / 2))) * kbytes; \
-                RW[i] = LCM_WLOAD(reinterpret_cast<const u32x4*>(b + off_));                             \
+                RW[i] = LCM_WLOAD(reinterpret_cast<const u32x4*>(LCM_CM_W(b, (rr < WR / 2 ? p.W : p.W2), off_)));                    \
             } else {                                                                                     \
-                RW[i] = LCM_WLOAD(reinterpret_cast<const u32x4*>(w_base + (size_t)(8 * i) * kbytes + off_)); \
+                RW[i] = LCM_WLOAD(reinterpret_cast<const u32x4*>(LCM_CM_W(w_base + (size_t)(8 * i) * kbytes, p.W, off_))); \
             }                                                                                            \
         }                                                                                                \
     }
-#if LCM_ABLATE == 3
+#if LCM_ABLATE >= 3
     u32x4 sink_ = {0u, 0u, 0u, 0u};
 #define LCM_STORE_CHUNK(RA, RW)                                                                          \
     {                                                                                                    \
@@ -166,7 +181,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs p) {
     const char* x_frag = smem + (wm * 32 + frow) * kRowBytes + fk;
     auto consume = [&]() {
 #pragma unroll 2
-        for (int ks = 0; ks < ((LCM_ABLATE == 1 || LCM_ABLATE == 3) ? 0 : KSTEPS); ++ks) {
+        for (int ks = 0; ks < ((LCM_ABLATE == 1 || LCM_ABLATE >= 3) ? 0 : KSTEPS); ++ks) {
             const int kb = ks * KSTEP_BYTES;
             typename Mma<T>::Frag w[TN], x[2];
 #pragma unroll
@@ -180,7 +195,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs p) {
         }
     };
 
-#if LCM_ABLATE == 3
+#if LCM_ABLATE >= 3
 #define __syncthreads() ((void)0)
 #endif
     const int nloc = c_end - c_begin;   // >= 1: every split owns at least one chunk (see make_plan)
@@ -205,101 +220,13 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs p) {
         }
     }
 
-#if LCM_ABLATE == 3
+#if LCM_ABLATE >= 3
 #undef __syncthreads
     if ((sink_.x ^ sink_.y ^ sink_.z ^ sink_.w) == 0x12345678u) acc[0][0][0] = 1.f;   // keeps the loads alive
 #endif
     // ---- epilogue: lane holds 4 consecutive columns of row m for each (tn, tm)
-    const int quad = 4 * (lane >> 4);
-    if constexpr (EPI == EPI_PARTIAL) {
-        float* slab = p.partial + (size_t)blockIdx.y * p.M * p.N;
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int n = blockIdx.x * BNR + wn * WR + tn * 16 + quad;
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm) {
-                const int m = m0 + wm * 32 + tm * 16 + (lane & 15);
-                if (m < p.M)
-                    *reinterpret_cast<float4*>(slab + (size_t)m * p.N + n) =
-                        make_float4(acc[tn][tm][0], acc[tn][tm][1], acc[tn][tm][2], acc[tn][tm][3]);
-            }
-        }
-        return;
-    } else {
-        const T* bias = reinterpret_cast<const T*>(p.bias);
-        const T* bias2 = reinterpret_cast<const T*>(p.bias2);
-        constexpr int TNO = DUAL ? TN / 2 : TN;   // output column tiles per wave
-#pragma unroll
-        for (int tn = 0; tn < TNO; ++tn) {
-            const int n = DUAL ? blockIdx.x * (BNR / 2) + wn * (WR / 2) + tn * 16 + quad
-                               : blockIdx.x * BNR + wn * WR + tn * 16 + quad;
-            float bv[4] = {0.f, 0.f, 0.f, 0.f}, bv2[4] = {0.f, 0.f, 0.f, 0.f}, gv[4] = {1.f, 1.f, 1.f, 1.f};
-            if (bias) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) bv[r] = Elem<T>::load(bias + n + r);
-            }
-            if constexpr (DUAL) {
-                if (bias2) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) bv2[r] = Elem<T>::load(bias2 + n + r);
-                }
-            }
-            if constexpr (EPI == LCMHIP_EPI_RESID) {
-                if (p.gate) {
-                    const float4 g = *reinterpret_cast<const float4*>(p.gate + n);
-                    gv[0] = g.x; gv[1] = g.y; gv[2] = g.z; gv[3] = g.w;
-                }
-            }
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm) {
-                const int m = m0 + wm * 32 + tm * 16 + (lane & 15);
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = acc[tn][tm][r] + bv[r];
-                if constexpr (EPI == LCMHIP_EPI_RESID) {
-                    // rows [M, M + extra_rows) take a constant instead of the product
-                    const bool real = m < p.M;
-                    const bool extra = !real && m < p.M + p.extra_rows;
-                    if (extra) {
-                        const float4 c = *reinterpret_cast<const float4*>(p.extra_const + n);
-                        v[0] = c.x; v[1] = c.y; v[2] = c.z; v[3] = c.w;
-                    }
-                    if (real || extra) {
-                        float4* dstp = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n);
-                        float4 o = *dstp;
-                        o.x += gv[0] * v[0]; o.y += gv[1] * v[1]; o.z += gv[2] * v[2]; o.w += gv[3] * v[3];
-                        *dstp = o;
-                    }
-                } else {
-                    if (m >= p.M) continue;
-                    if constexpr (EPI == LCMHIP_EPI_RELU) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                    }
-                    if constexpr (DUAL) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float g = v[r];
-                            const float in = acc[tn + TN / 2][tm][r] + bv2[r];
-                            v[r] = in * (g / (1.f + __expf(-g)));
-                        }
-                    }
-                    size_t oidx;
-                    if (p.out_rows == nullptr) oidx = (size_t)m * p.ldo + n;
-                    else if (p.out_head_cap > 0) oidx = kv_cache_offset(p.out_rows[m], n, p.out_head_cap, p.N);
-                    else oidx = (size_t)p.out_rows[m] * p.ldo + n;
-                    if constexpr (EPI == LCMHIP_EPI_STORE_F32 || sizeof(T) == 4) {
-                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + oidx) = make_float4(v[0], v[1], v[2], v[3]);
-                    } else {
-                        uint2 o;
-                        o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                        o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-                        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + oidx) = o;
-                    }
-                }
-            }
-        }
-    }
+    gemm_epilogue<T, EPI, 2, TN>(p, acc, m0 + wm * 32, DUAL ? blockIdx.x * (BNR / 2) + wn * (WR / 2) : blockIdx.x * BNR + wn * WR,
+                                 blockIdx.y, lane);
 }
 
 // Sums the split-K slabs and applies a (non-dual) epilogue.  One lane = 4 consecutive columns.
@@ -355,6 +282,10 @@ __global__ __launch_bounds__(256) void k_splitk_finish(GemmArgs p, int splits) {
 }
 
 // ---- host-side dispatch -------------------------------------------------------------------------------
+bool gemm_big_applicable(const GemmArgs& a);                 // gemm_big.hip: many-row bf16 problems
+int gemm_big_splits(const GemmArgs& a, int max_splits);
+int launch_gemm_big(const GemmArgs& a, int epi, int splits, int m_rows, hipStream_t st);
+
 struct Plan {
     int wm, wn, tn;    // wave grid and weight tiles per wave
     int n_tiles, m_tiles, splits;
@@ -452,6 +383,7 @@ static int check_args(const GemmArgs& a) {
 
 int gemm_partial_splits(const GemmArgs& a) {
     if (check_args(a) != LCMHIP_OK) return -1;
+    if (gemm_big_applicable(a)) return gemm_big_splits(a, a.max_splits);
     return make_plan(a, true).splits;
 }
 
@@ -459,6 +391,12 @@ int gemm_partial_splits(const GemmArgs& a) {
 int launch_gemm_partial(const GemmArgs& a, int* splits, hipStream_t st) {
     LCM_TRY(check_args(a));
     LCM_REQUIRE(a.partial != nullptr && a.epilogue != LCMHIP_EPI_SWIGLU, "gemm: partial mode needs a slab and a linear epilogue");
+    if (gemm_big_applicable(a)) {
+        const int s = gemm_big_splits(a, a.max_splits);
+        LCM_REQUIRE((size_t)s * a.M * a.N * 4 <= a.partial_bytes, "gemm: split-K slab too small");
+        *splits = s;
+        return launch_gemm_big(a, EPI_PARTIAL, s, a.M, st);
+    }
     const Plan pl = make_plan(a, true);
     LCM_REQUIRE((size_t)pl.splits * a.M * a.N * 4 <= a.partial_bytes, "gemm: split-K slab too small");
     *splits = pl.splits;
@@ -469,6 +407,15 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     LCM_TRY(check_args(a));
     LCM_REQUIRE(a.out != nullptr && a.ldo % 4 == 0 && ((uintptr_t)a.out % 16) == 0, "gemm: output must be 16-byte aligned");
     const bool can_split = a.partial != nullptr && a.epilogue != LCMHIP_EPI_SWIGLU;
+    if (gemm_big_applicable(a)) {
+        int s = can_split ? gemm_big_splits(a, a.max_splits) : 1;
+        if ((size_t)s * a.M * a.N * 4 > a.partial_bytes) s = 1;
+        if (s > 1) {
+            LCM_TRY(launch_gemm_big(a, EPI_PARTIAL, s, a.M, st));
+            return launch_finish<bf16_t>(a, s, st);
+        }
+        return launch_gemm_big(a, a.epilogue, 1, a.M + (a.epilogue == LCMHIP_EPI_RESID ? a.extra_rows : 0), st);
+    }
     Plan pl = make_plan(a, can_split);
     if (can_split && (size_t)pl.splits * a.M * a.N * 4 > a.partial_bytes) pl.splits = 1;
     if (pl.splits > 1) {

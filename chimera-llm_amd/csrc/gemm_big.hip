@@ -1,0 +1,144 @@
+// C = A * W^T for bf16 operands and MANY rows (M >= 256: context prefill, large document batches, schedule
+// tables): a matrix-core-bound GEMM, unlike the weight-streaming kernel of gemm.hip.
+//
+// Tile 128 (rows) x 128 (weight rows) x 64 (K) per workgroup of 4 waves (2 x 2); each wave owns 64 x 64 =
+// 4 x 4 accumulator tiles of v_mfma_f32_16x16x32_bf16 (weight rows = A operand, activation rows = B operand,
+// same accumulator convention as gemm.hip, so the epilogue is shared).  Both operands are K-contiguous, so a
+// tile row is 128 contiguous bytes.  Staging is global -> LDS by LDS-DMA (global_load_lds, 16 bytes per lane):
+// one wave instruction fills 8 rows x 128 B of the stage, lane l -> (row l / 8, 16-byte slot l % 8).  The LDS
+// image stays lane-linear; bank conflicts of the fragment reads (16 rows x one 16-byte slot) are removed by
+// swizzling on the SOURCE side: slot s of row r holds the K piece s ^ (r % 8).  Two stages: the DMA of K tile
+// t + 1 runs while the matrix cores consume tile t; one barrier per K tile.
+#include "common.h"
+#include "gemm_epilogue.h"
+
+namespace lcmhip {
+
+namespace {
+constexpr int kBM = 128, kBN = 128;
+constexpr int kRowB = 128;                      // bytes of K per tile row and stage (64 bf16)
+constexpr int kStageB = (kBM + kBN) * kRowB;    // 32 KiB
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+}  // namespace
+
+template <int EPI>
+__global__ __launch_bounds__(256) void k_gemm_big(GemmArgs p) {
+    constexpr bool DUAL = (EPI == LCMHIP_EPI_SWIGLU);
+    __shared__ __attribute__((aligned(1024))) char smem[2 * kStageB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int m0 = blockIdx.z * kBM;
+    const size_t kbytes = (size_t)p.K * 2;
+    const int nk = (int)(kbytes / kRowB);
+    const int kps = (nk + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int k_begin = blockIdx.y * kps;
+    const int k_end = min(nk, k_begin + kps);
+
+    // ---- staging plan: wave w fills row groups w, w + 4, ... (8 rows each); groups 0..15 = activation rows,
+    // 16..31 = weight rows.  This lane's row inside a group is lane / 8, its slot lane % 8 receives K piece
+    // (lane % 8) ^ (lane / 8).
+    const int srow = lane >> 3;
+    const size_t piece_off = (size_t)(((lane & 7) ^ srow) * 16);
+    const char* src[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int grp = wid + 4 * j;            // j < 4: activations, j >= 4: weights (wave-uniform)
+        if (j < 4) {
+            int m = m0 + grp * 8 + srow;
+            m = m < p.M ? m : p.M - 1;          // rows past the end repeat the last row; never stored
+            src[j] = reinterpret_cast<const char*>(p.A) + (size_t)m * p.lda * 2 + piece_off;
+        } else {
+            const int t = (grp - 16) * 8 + srow;   // weight row inside the tile, 0..127
+            if constexpr (DUAL) {
+                // wave column wn' = t / 64 owns 32 gate rows followed by 32 inner rows of the same 32 outputs
+                const int wcol = t >> 6, rr = t & 63;
+                const size_t row = (size_t)blockIdx.x * (kBN / 2) + wcol * 32 + (rr & 31);
+                src[j] = reinterpret_cast<const char*>(rr < 32 ? p.W : p.W2) + row * kbytes + piece_off;
+            } else {
+                src[j] = reinterpret_cast<const char*>(p.W) + ((size_t)blockIdx.x * kBN + t) * kbytes + piece_off;
+            }
+        }
+    }
+    auto stage = [&](int kt, int buf) {
+        const size_t koff = (size_t)kt * kRowB;
+        char* dst = smem + buf * kStageB;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + koff), (lptr_t)(dst + (wid + 4 * j) * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment addresses: row = tile row base + lane % 16, K piece of k-step ks = 4 * ks + lane / 16
+    const int frow = lane & 15;
+    const int fsw = frow & 7;
+    const int x_row0 = wm * 64 + frow;
+    const int w_row0 = kBM + wn * 64 + frow;
+
+    stage(k_begin, 0);
+    for (int kt = k_begin; kt < k_end; ++kt) {
+        const int buf = (kt - k_begin) & 1;
+        // tile kt has landed for every wave, and every wave is done reading the other stage
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < k_end) stage(kt + 1, buf ^ 1);
+        const char* base = smem + buf * kStageB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int slot = ((4 * ks + (lane >> 4)) ^ fsw) * 16;
+            bf16x8 w[4], x[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) w[t] = *reinterpret_cast<const bf16x8*>(base + (w_row0 + 16 * t) * kRowB + slot);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) x[t] = *reinterpret_cast<const bf16x8*>(base + (x_row0 + 16 * t) * kRowB + slot);
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[tn], x[tm], acc[tn][tm], 0, 0, 0);
+        }
+    }
+
+    gemm_epilogue<bf16_t, EPI, 4, 4>(p, acc, m0 + wm * 64, DUAL ? blockIdx.x * (kBN / 2) + wn * 32 : blockIdx.x * kBN + wn * 64,
+                                     blockIdx.y, lane);
+}
+
+bool gemm_big_applicable(const GemmArgs& a) {
+    static const int min_rows = [] { const char* e = getenv("LCMHIP_BIG_MIN_ROWS"); return e ? atoi(e) : 256; }();
+    const int wrows = a.epilogue == LCMHIP_EPI_SWIGLU ? 2 * a.N : a.N;
+    return a.dtype == LCMHIP_BF16 && a.M >= min_rows && a.K % 64 == 0 && wrows % kBN == 0 && a.lda % 8 == 0;
+}
+
+// epi: LCMHIP_EPI_* or EPI_PARTIAL; splits >= 1 (only with EPI_PARTIAL); m_rows: rows the row tiles must cover
+int launch_gemm_big(const GemmArgs& a, int epi, int splits, int m_rows, hipStream_t st) {
+    const int wrows = epi == LCMHIP_EPI_SWIGLU ? 2 * a.N : a.N;
+    dim3 grid(wrows / kBN, splits, (m_rows + kBM - 1) / kBM), block(256);
+    switch (epi) {
+        case LCMHIP_EPI_STORE: hipLaunchKernelGGL((k_gemm_big<LCMHIP_EPI_STORE>), grid, block, 0, st, a); break;
+        case LCMHIP_EPI_STORE_F32: hipLaunchKernelGGL((k_gemm_big<LCMHIP_EPI_STORE_F32>), grid, block, 0, st, a); break;
+        case LCMHIP_EPI_RELU: hipLaunchKernelGGL((k_gemm_big<LCMHIP_EPI_RELU>), grid, block, 0, st, a); break;
+        case LCMHIP_EPI_SWIGLU: hipLaunchKernelGGL((k_gemm_big<LCMHIP_EPI_SWIGLU>), grid, block, 0, st, a); break;
+        case LCMHIP_EPI_RESID: hipLaunchKernelGGL((k_gemm_big<LCMHIP_EPI_RESID>), grid, block, 0, st, a); break;
+        case EPI_PARTIAL: hipLaunchKernelGGL((k_gemm_big<EPI_PARTIAL>), grid, block, 0, st, a); break;
+        default: return fail(LCMHIP_ERR_INVALID, "gemm: unknown epilogue");
+    }
+    LCM_HIP_CHECK(hipGetLastError());
+    return LCMHIP_OK;
+}
+
+// K splits for the split-K (slab) form: enough workgroups for the chip, at least 8 K tiles per split
+int gemm_big_splits(const GemmArgs& a, int max_splits) {
+    const int tiles = (a.N / kBN) * ((a.M + kBM - 1) / kBM);
+    const int nk = a.K / 64;
+    int s = 1;
+    while (tiles * s < 256 && nk % (s * 2) == 0 && nk / (s * 2) >= 8 && s * 2 <= (max_splits > 0 ? max_splits : 64)) s *= 2;   // splits divide the K tiles
+    return s;
+}
+
+}  // namespace lcmhip

@@ -1,0 +1,39 @@
+"""TFLOP/s of lcmhip_gemm at many-row shapes (bf16, random operands, hot caches)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from lcm import _hip
+dev = torch.device("cuda:0")
+st = _hip.stream_ptr(dev)
+ITERS = 20
+
+def bench(M, N, K, epi):
+    A = torch.randn(M, K, device=dev).bfloat16()
+    W = (torch.randn(N, K, device=dev) * 0.02).bfloat16()
+    W2 = (torch.randn(N, K, device=dev) * 0.02).bfloat16() if epi == _hip.EPI_SWIGLU else None
+    out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    def run():
+        _hip.check(_hip.lib.lcmhip_gemm(_hip.ptr(A), K, _hip.ptr(W), _hip.ptr(W2), None, None, None, _hip.ptr(out), N,
+                                        M, N, K, epi, _hip.BF16, None, 0, st))
+    for _ in range(3): run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(ITERS): run()
+    e1.record(); torch.cuda.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / ITERS
+    flops = 2.0 * M * N * K * (2 if epi == _hip.EPI_SWIGLU else 1)
+    ref = torch.nn.functional.linear(A, W)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(ITERS): torch.nn.functional.linear(A, W)
+    e1.record(); torch.cuda.synchronize()
+    us_t = 1e3 * e0.elapsed_time(e1) / ITERS
+    print(f"M={M:5d} N={N:5d} K={K:5d} epi={epi}  {us:8.1f} us  {flops / us / 1e6:7.1f} TFLOP/s   (torch/hipBLASLt linear: {2.0*M*N*K / us_t / 1e6:7.1f})", flush=True)
+
+for M in (256, 1024, 4096):
+    bench(M, 2048, 2048, _hip.EPI_STORE)
+    bench(M, 5632, 2048, _hip.EPI_SWIGLU)
+    bench(M, 2048, 5632, _hip.EPI_STORE)
+bench(4096, 4096, 4096, _hip.EPI_STORE)
+bench(8192, 8192, 8192, _hip.EPI_STORE)

@@ -95,6 +95,30 @@ def _gemm(hip, A, W, W2, bias, bias2, gate, out, epi, ws=None):
 @pytest.mark.parametrize("N,K", [(256, 256), (1024, 2048), (768, 256), (2048, 5632)])
 @pytest.mark.parametrize("split", [False, True])
 def test_gemm_epilogues(hip, dtype, M, N, K, split):
+    _check_epilogues(hip, dtype, M, N, K, split)
+
+
+@pytest.mark.parametrize("M", [256, 300, 1000])
+@pytest.mark.parametrize("N,K", [(256, 256), (2048, 2048), (1024, 5632)])
+@pytest.mark.parametrize("split", [False, True])
+def test_gemm_many_rows(hip, M, N, K, split):
+    """M >= 256 in bf16 takes the 128 x 128 matrix-core tile kernel (LDS-DMA staging)."""
+    _check_epilogues(hip, torch.bfloat16, M, N, K, split)
+
+
+def test_gemm_many_rows_identity_and_row_map(hip):
+    """A = I against an asymmetric integer W (exact in bf16) through the 128 x 128 kernel, plain and scattered
+    through a row map into the (slot, head, position, 128) cache layout."""
+    M = K = 512
+    N = 256
+    A = torch.eye(M, K).cuda().to(torch.bfloat16)
+    W = (torch.arange(N).view(N, 1) % 7 - 3 + 2 * (torch.arange(K).view(1, K) % 5)).float().cuda().to(torch.bfloat16)
+    out = torch.empty(M, N, device="cuda")
+    _gemm(hip, A, W, None, None, None, None, out, hip.EPI_STORE_F32)
+    assert torch.equal(out.cpu(), W.float().cpu().T)
+
+
+def _check_epilogues(hip, dtype, M, N, K, split):
     torch.manual_seed(M * 1000 + N + K)
     ws = torch.empty(12 * M * N, device="cuda") if split else None
     _gemm = functools.partial(globals()["_gemm"], ws=ws)   # same calls, optional split-K scratch
