@@ -8,35 +8,51 @@ namespace lcmhip {
 // ------------------------------------------------------------------------------------------------
 // SONAR normalizer: y = (x - center) / scale  [clamp]   |   y = [clamp](x) * scale + center
 // ------------------------------------------------------------------------------------------------
+// Lane i handles the 8-element vectors i, i + stride, ...; the launcher makes the stride a multiple of the row
+// length, so a lane stays on one column group: center / scale (and 1 / scale) are loaded once, and U vectors
+// are in flight per iteration.
 template <typename TI, typename TO, typename TP, bool INVERSE>
 __global__ __launch_bounds__(256) void k_normalizer(const TI* __restrict__ x, const TP* __restrict__ center,
                                                     const TP* __restrict__ scale, const TP* __restrict__ cmin,
                                                     const TP* __restrict__ cmax, TO* __restrict__ y, int64_t n_vec,
                                                     int vec_per_row) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += (int64_t)gridDim.x * blockDim.x) {
-        const int col = (int)(i % vec_per_row) * 8;
-        float v[8], c[8], s[8];
-        load8<TI>(x + i * 8, v);
-        load8<TP>(center + col, c);
-        load8<TP>(scale + col, s);
-        if (cmin != nullptr) {
-            float lo[8], hi[8];
-            load8<TP>(cmin + col, lo);
-            load8<TP>(cmax + col, hi);
+    constexpr int U = 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int col = (int)(i0 % vec_per_row) * 8;
+    float c[8], s[8], lo[8], hi[8];
+    load8<TP>(center + col, c);
+    load8<TP>(scale + col, s);
+    const bool clip = cmin != nullptr;
+    if (clip) {
+        load8<TP>(cmin + col, lo);
+        load8<TP>(cmax + col, hi);
+    }
+    for (int64_t i = i0; i < n_vec; i += U * stride) {
+        float v[U][8];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (i + u * stride < n_vec) load8<TI>(x + (i + u * stride) * 8, v[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (i + u * stride >= n_vec) break;
             if (INVERSE) {
+                if (clip) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = fminf(fmaxf(v[j], lo[j]), hi[j]);
+                    for (int j = 0; j < 8; ++j) v[u][j] = fminf(fmaxf(v[u][j], lo[j]), hi[j]);
+                }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = v[j] * s[j] + c[j];
+                for (int j = 0; j < 8; ++j) v[u][j] = v[u][j] * s[j] + c[j];
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = fminf(fmaxf((v[j] - c[j]) / s[j], lo[j]), hi[j]);
-            }
-        } else {
+                for (int j = 0; j < 8; ++j) v[u][j] = (v[u][j] - c[j]) / s[j];
+                if (clip) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = INVERSE ? v[j] * s[j] + c[j] : (v[j] - c[j]) / s[j];
+                    for (int j = 0; j < 8; ++j) v[u][j] = fminf(fmaxf(v[u][j], lo[j]), hi[j]);
+                }
+            }
+            store8<TO>(y + (i + u * stride) * 8, v[u]);
         }
-        store8<TO>(y + i * 8, v);
     }
 }
 
@@ -47,13 +63,23 @@ static int grid_for(int64_t n_items, int block) {
     return (int)g;
 }
 
+// Grid of the normalizer: grid * 256 lanes must be a multiple of the vectors per row whenever a lane makes
+// more than one pass, so that it stays on its column group.
+static int normalizer_grid(int64_t n_vec, int vec_per_row) {
+    int64_t g = (n_vec + 255) / 256;
+    if (g <= 2048) return (int)(g < 1 ? 1 : g);   // one pass
+    g = 2048;
+    while ((g * 256) % vec_per_row != 0) --g;     // vec_per_row <= 1024 here: terminates at a multiple
+    return (int)g;
+}
+
 int launch_normalize(const void* x, const void* center, const void* scale, const void* cmin, const void* cmax,
                      void* y, int64_t rows, int dim, int dtype, bool inverse, hipStream_t st) {
-    LCM_REQUIRE(dim % 8 == 0 && rows >= 0, "normalizer: dim must be a multiple of 8");
+    LCM_REQUIRE(dim % 8 == 0 && dim <= 8192 && rows >= 0, "normalizer: dim must be a multiple of 8, at most 8192");
     LCM_REQUIRE((cmin == nullptr) == (cmax == nullptr), "normalizer: clip_min and clip_max go together");
     if (rows == 0) return LCMHIP_OK;
     const int64_t n_vec = rows * (dim / 8);
-    const int g = grid_for(n_vec, 256);
+    const int g = normalizer_grid(n_vec, dim / 8);
 #define LCM_NORMALIZER(T, INV)                                                                             \
     hipLaunchKernelGGL((k_normalizer<T, T, T, INV>), dim3(g), dim3(256), 0, st, (const T*)x, (const T*)center, \
                        (const T*)scale, (const T*)cmin, (const T*)cmax, (T*)y, n_vec, dim / 8)
@@ -74,7 +100,7 @@ int launch_normalize_f32_in(const float* x, const void* center, const void* scal
     LCM_REQUIRE(dim % 8 == 0, "normalizer: dim must be a multiple of 8");
     if (rows == 0) return LCMHIP_OK;
     const int64_t n_vec = rows * (dim / 8);
-    const int g = grid_for(n_vec, 256);
+    const int g = normalizer_grid(n_vec, dim / 8);
     if (dtype == LCMHIP_BF16)
         hipLaunchKernelGGL((k_normalizer<float, bf16_t, bf16_t, false>), dim3(g), dim3(256), 0, st, x,
                            (const bf16_t*)center, (const bf16_t*)scale, (const bf16_t*)nullptr,
@@ -92,7 +118,7 @@ int launch_denormalize_f32_out(const float* x0, const void* center, const void* 
     LCM_REQUIRE(dim % 8 == 0, "normalizer: dim must be a multiple of 8");
     if (rows == 0) return LCMHIP_OK;
     const int64_t n_vec = rows * (dim / 8);
-    const int g = grid_for(n_vec, 256);
+    const int g = normalizer_grid(n_vec, dim / 8);
     if (dtype == LCMHIP_BF16)
         hipLaunchKernelGGL((k_normalizer<float, float, bf16_t, true>), dim3(g), dim3(256), 0, st, x0,
                            (const bf16_t*)center, (const bf16_t*)scale, (const bf16_t*)nullptr,
@@ -231,6 +257,87 @@ __global__ __launch_bounds__(NT) void k_norm_modulate(float* __restrict__ x, con
     }
 }
 
+// Many rows, nothing pending: one wave per row (4 rows per workgroup), the row in registers, statistics by wave
+// shuffles only -- no LDS, no barrier.  dim <= 4096, dim % 256 == 0.
+template <typename T, int KIND, int NV>
+__global__ __launch_bounds__(256) void k_norm_rows(const float* __restrict__ x, const T* __restrict__ w,
+                                                   const T* __restrict__ b, const float* __restrict__ shift,
+                                                   const float* __restrict__ scale, T* __restrict__ y, int rows, float eps) {
+    constexpr int dim = NV * 256;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;   // wave-uniform
+    const float* xr = x + (size_t)row * dim;
+    float4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(xr + (lane + 64 * i) * 4);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        s += KIND == LCMHIP_NORM_RMS ? v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w
+                                     : v[i].x + v[i].y + v[i].z + v[i].w;
+    s = wave_sum(s);
+    float mean = 0.f, rstd;
+    if (KIND == LCMHIP_NORM_RMS) {
+        rstd = rsqrtf(s / dim + eps);
+    } else {
+        mean = s / dim;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+            q += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
+        }
+        q = wave_sum(q);
+        rstd = rsqrtf(q / dim + eps);
+    }
+    T* yr = y + (size_t)row * dim;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = (lane + 64 * i) * 4;
+        float o[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+        float sc[4] = {0.f, 0.f, 0.f, 0.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+        if (scale != nullptr) {
+            const float4 a = *reinterpret_cast<const float4*>(scale + col);
+            const float4 h = *reinterpret_cast<const float4*>(shift + col);
+            sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w;
+            sh[0] = h.x; sh[1] = h.y; sh[2] = h.z; sh[3] = h.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float pw = Elem<T>::load(w + col + j);
+            const float pb = (KIND == LCMHIP_NORM_LAYERNORM && b != nullptr) ? Elem<T>::load(b + col + j) : 0.f;
+            const float t = (o[j] - mean) * rstd * pw + pb;
+            o[j] = t * (1.f + sc[j]) + sh[j];
+        }
+        if (sizeof(T) == 4) {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(yr) + col) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+            uint2 pk;
+            pk.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
+            pk.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(yr) + col) = pk;
+        }
+    }
+}
+
+template <typename T, int KIND>
+static bool launch_norm_rows(const float* x, const void* w, const void* b, const float* shift, const float* scale, void* y,
+                             int rows, int dim, float eps, hipStream_t st) {
+    const dim3 grid((rows + 3) / 4), block(256);
+#define LCM_ROWS(NV)                                                                                             \
+    hipLaunchKernelGGL((k_norm_rows<T, KIND, NV>), grid, block, 0, st, x, (const T*)w, (const T*)b, shift, scale, \
+                       (T*)y, rows, eps)
+    switch (dim) {
+        case 256: LCM_ROWS(1); return true;
+        case 1024: LCM_ROWS(4); return true;
+        case 2048: LCM_ROWS(8); return true;
+        case 4096: LCM_ROWS(16); return true;
+        default: return false;
+    }
+#undef LCM_ROWS
+}
+
 int launch_norm_modulate(float* x, const void* w, const void* b, const float* shift, const float* scale,
                          void* y, int rows_total, int rows_norm, int dim, int norm_kind, float eps, int dtype,
                          const Pending* pend, hipStream_t st) {
@@ -248,6 +355,19 @@ int launch_norm_modulate(float* x, const void* w, const void* b, const float* sh
     }
     const int rows = pend ? rows_total : rows_norm;
     if (rows <= 0) return LCMHIP_OK;
+    if (!pend && rows >= 1024) {
+        bool done = false;
+        if (dtype == LCMHIP_BF16)
+            done = norm_kind == LCMHIP_NORM_RMS ? launch_norm_rows<bf16_t, LCMHIP_NORM_RMS>(x, w, b, shift, scale, y, rows, dim, eps, st)
+                                                : launch_norm_rows<bf16_t, LCMHIP_NORM_LAYERNORM>(x, w, b, shift, scale, y, rows, dim, eps, st);
+        else if (dtype == LCMHIP_F32)
+            done = norm_kind == LCMHIP_NORM_RMS ? launch_norm_rows<float, LCMHIP_NORM_RMS>(x, w, b, shift, scale, y, rows, dim, eps, st)
+                                                : launch_norm_rows<float, LCMHIP_NORM_LAYERNORM>(x, w, b, shift, scale, y, rows, dim, eps, st);
+        if (done) {
+            LCM_HIP_CHECK(hipGetLastError());
+            return LCMHIP_OK;
+        }
+    }
     // wide rows: 512 lanes per row keep twice as many loads in flight per CU
 #define LCM_NORM(T, KIND)                                                                                      \
     if (dim >= 2048)                                                                                           \

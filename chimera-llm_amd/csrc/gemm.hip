@@ -83,14 +83,16 @@ constexpr int kRowBytes = kChunkBytes + 16;  // padded LDS row
 
 // WM x WN waves; each wave owns 32 activation rows x (16 * TN) weight rows.
 template <typename T, int WM, int WN, int TN, int EPI>
-__global__ __launch_bounds__(256) void k_gemm(GemmArgs p) {
+__global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs p) {
     constexpr bool DUAL = (EPI == LCMHIP_EPI_SWIGLU);
     constexpr int WR = 16 * TN;                  // weight rows per wave
     constexpr int BM = 32 * WM, BNR = WR * WN;   // activation rows / weight rows per tile
     constexpr int R = BM + BNR;
     constexpr int KSTEP_BYTES = 4 * Mma<T>::kLaneBytes;
     constexpr int KSTEPS = kChunkBytes / KSTEP_BYTES;
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per workgroup");
+    constexpr int RP = 2 * WM * WN;              // tile rows one pass of the staging loads covers (32 lanes per row)
+    static_assert(!DUAL || (WR / 2) % RP == 0, "a staging pass must not straddle the gate / inner halves");
 
     __shared__ __attribute__((aligned(16))) char smem[R * kRowBytes];
 
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs p) {
     // Lane (r0 = tid / 32, c = tid % 32) moves the 16-byte piece c of tile rows r0, r0 + 8, r0 + 16, ...:
     // 32 consecutive lanes cover one 512-byte row segment.  Row addresses are recomputed from two
     // scalars per operand (no per-piece pointer arrays, which the compiler would keep in scratch).
-    constexpr int NA = BM / 8, NW = BNR / 8;
+    constexpr int NA = BM / RP, NW = BNR / RP;
     const int r0 = tid >> 5;
     const size_t col_off = (size_t)(tid & 31) * 16 + (size_t)c_begin * kChunkBytes;
     const char* a_base = reinterpret_cast<const char*>(p.A) + col_off;
@@ -137,18 +139,18 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs p) {
     {                                                                                                    \
         const size_t off_ = (OFF);                                                                       \
         _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                 \
-            int m = m0 + r0 + 8 * i;                                                                     \
+            int m = m0 + r0 + RP * i;                                                                    \
             m = m < p.M ? m : p.M - 1;                                                                   \
             RA[i] = *reinterpret_cast<const u32x4*>(LCM_CM_A(a_base + (size_t)m * a_stride, off_));      \
         }                                                                                                \
         _Pragma("unroll") for (int i = 0; i < NW; ++i) {                                                 \
             if constexpr (DUAL) {                                                                        \
                 /* tile row 8i + r0 belongs to wave (8i) / WR; a wave's first WR/2 rows = gate, rest = inner */ \
-                const int grp = (8 * i) / WR, rr = (8 * i) % WR;                                         \
+                const int grp = (RP * i) / WR, rr = (RP * i) % WR;                                       \
                 const char* b = (rr < WR / 2 ? w_base : w2_base) + (size_t)(grp * (WR / 2) + (rr % (WR / 2))) * kbytes; \
                 RW[i] = LCM_WLOAD(reinterpret_cast<const u32x4*>(LCM_CM_W(b, (rr < WR / 2 ? p.W : p.W2), off_)));                    \
             } else {                                                                                     \
-                RW[i] = LCM_WLOAD(reinterpret_cast<const u32x4*>(LCM_CM_W(w_base + (size_t)(8 * i) * kbytes, p.W, off_))); \
+                RW[i] = LCM_WLOAD(reinterpret_cast<const u32x4*>(LCM_CM_W(w_base + (size_t)(RP * i) * kbytes, p.W, off_))); \
             }                                                                                            \
         }                                                                                                \
     }
@@ -163,9 +165,9 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs p) {
 #define LCM_STORE_CHUNK(RA, RW)                                                                          \
     {                                                                                                    \
         _Pragma("unroll") for (int i = 0; i < NA; ++i)                                                   \
-            *reinterpret_cast<u32x4*>(lds_dst + (8 * i) * kRowBytes) = RA[i];                            \
+            *reinterpret_cast<u32x4*>(lds_dst + (RP * i) * kRowBytes) = RA[i];                           \
         _Pragma("unroll") for (int i = 0; i < NW; ++i)                                                   \
-            *reinterpret_cast<u32x4*>(lds_dst + (BM + 8 * i) * kRowBytes) = RW[i];                       \
+            *reinterpret_cast<u32x4*>(lds_dst + (BM + RP * i) * kRowBytes) = RW[i];                      \
     }
 #endif
 
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(256) void k_splitk_finish(GemmArgs p, int splits) {
 }
 
 // ---- host-side dispatch -------------------------------------------------------------------------------
-bool gemm_big_applicable(const GemmArgs& a);                 // gemm_big.hip: many-row bf16 problems
+bool gemm_big_applicable(const GemmArgs& a, bool may_split);   // gemm_big.hip: many-row bf16 problems
 int gemm_big_splits(const GemmArgs& a, int max_splits);
 int launch_gemm_big(const GemmArgs& a, int epi, int splits, int m_rows, hipStream_t st);
 
@@ -292,7 +294,7 @@ struct Plan {
 };
 
 static int tall_mode() {
-    static const int v = [] { const char* e = getenv("LCMHIP_TALL"); return e ? atoi(e) : 0; }();
+    static const int v = [] { const char* e = getenv("LCMHIP_TALL"); return e ? atoi(e) : 2; }();   // 0: 64 x 64 tiles only; 1: 128 x 64 with 4 waves; 2 (default): with 8 waves
     return v;
 }
 
@@ -303,7 +305,8 @@ static Plan make_plan(const GemmArgs& a, bool may_split) {
     Plan pl{};
     if (rows <= 32 && wrows % 256 == 0) { pl.wm = 1; pl.wn = 4; pl.tn = 4; }         // 32 x 256
     else if (rows <= 64 && wrows % 128 == 0 && wrows >= 128 * 192) { pl.wm = 2; pl.wn = 2; pl.tn = 4; }   // 64 x 128
-    else if (rows > 64 && tall_mode() != 0) { pl.wm = 4; pl.wn = 1; pl.tn = 4; }      // 128 x 64: every weight row read by one workgroup
+    else if (rows > 64 && tall_mode() == 1) { pl.wm = 4; pl.wn = 1; pl.tn = 4; }      // 128 x 64, 4 waves
+    else if (rows > 64 && tall_mode() == 2) { pl.wm = 4; pl.wn = 2; pl.tn = 2; }      // 128 x 64, 8 waves: every weight row read by one workgroup
     else { pl.wm = 2; pl.wn = 2; pl.tn = 2; }                                        // 64 x 64, two per CU
     const int bm = 32 * pl.wm, bnr = 16 * pl.tn * pl.wn;
     pl.n_tiles = wrows / bnr;
@@ -329,7 +332,7 @@ static Plan make_plan(const GemmArgs& a, bool may_split) {
 
 template <typename T, int WM, int WN, int TN>
 static int launch_cfg(const GemmArgs& a, const Plan& pl, int epi, hipStream_t st) {
-    dim3 grid(pl.n_tiles, pl.splits, pl.m_tiles), block(256);
+    dim3 grid(pl.n_tiles, pl.splits, pl.m_tiles), block(64 * WM * WN);
     switch (epi) {
         case LCMHIP_EPI_STORE: hipLaunchKernelGGL((k_gemm<T, WM, WN, TN, LCMHIP_EPI_STORE>), grid, block, 0, st, a); break;
         case LCMHIP_EPI_STORE_F32: hipLaunchKernelGGL((k_gemm<T, WM, WN, TN, LCMHIP_EPI_STORE_F32>), grid, block, 0, st, a); break;
@@ -346,6 +349,7 @@ static int launch_cfg(const GemmArgs& a, const Plan& pl, int epi, hipStream_t st
 template <typename T>
 static int launch_plan(const GemmArgs& a, const Plan& pl, int epi, hipStream_t st) {
     if (pl.wm == 1) return launch_cfg<T, 1, 4, 4>(a, pl, epi, st);
+    if (pl.wm == 4 && pl.wn == 2) return launch_cfg<T, 4, 2, 2>(a, pl, epi, st);
     if (pl.wm == 4) return launch_cfg<T, 4, 1, 4>(a, pl, epi, st);
     if (pl.tn == 4) return launch_cfg<T, 2, 2, 4>(a, pl, epi, st);
     return launch_cfg<T, 2, 2, 2>(a, pl, epi, st);
@@ -383,7 +387,7 @@ static int check_args(const GemmArgs& a) {
 
 int gemm_partial_splits(const GemmArgs& a) {
     if (check_args(a) != LCMHIP_OK) return -1;
-    if (gemm_big_applicable(a)) return gemm_big_splits(a, a.max_splits);
+    if (gemm_big_applicable(a, true)) return gemm_big_splits(a, a.max_splits);
     return make_plan(a, true).splits;
 }
 
@@ -391,7 +395,7 @@ int gemm_partial_splits(const GemmArgs& a) {
 int launch_gemm_partial(const GemmArgs& a, int* splits, hipStream_t st) {
     LCM_TRY(check_args(a));
     LCM_REQUIRE(a.partial != nullptr && a.epilogue != LCMHIP_EPI_SWIGLU, "gemm: partial mode needs a slab and a linear epilogue");
-    if (gemm_big_applicable(a)) {
+    if (gemm_big_applicable(a, true)) {
         const int s = gemm_big_splits(a, a.max_splits);
         LCM_REQUIRE((size_t)s * a.M * a.N * 4 <= a.partial_bytes, "gemm: split-K slab too small");
         *splits = s;
@@ -407,7 +411,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     LCM_TRY(check_args(a));
     LCM_REQUIRE(a.out != nullptr && a.ldo % 4 == 0 && ((uintptr_t)a.out % 16) == 0, "gemm: output must be 16-byte aligned");
     const bool can_split = a.partial != nullptr && a.epilogue != LCMHIP_EPI_SWIGLU;
-    if (gemm_big_applicable(a)) {
+    if (gemm_big_applicable(a, can_split)) {
         int s = can_split ? gemm_big_splits(a, a.max_splits) : 1;
         if ((size_t)s * a.M * a.N * 4 > a.partial_bytes) s = 1;
         if (s > 1) {

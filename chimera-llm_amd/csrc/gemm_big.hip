@@ -109,10 +109,25 @@ __global__ __launch_bounds__(256) void k_gemm_big(GemmArgs p) {
                                      blockIdx.y, lane);
 }
 
-bool gemm_big_applicable(const GemmArgs& a) {
+// K splits for the split-K (slab) form: enough workgroups for the chip, at least 8 K tiles per split, and the
+// splits divide the K tiles
+int gemm_big_splits(const GemmArgs& a, int max_splits) {
+    const int tiles = (a.N / kBN) * ((a.M + kBM - 1) / kBM);
+    const int nk = a.K / 64;
+    int s = 1;
+    while (tiles * s < 256 && nk % (s * 2) == 0 && nk / (s * 2) >= 8 && s * 2 <= (max_splits > 0 ? max_splits : 64)) s *= 2;
+    return s;
+}
+
+// The 128 x 128 kernel pays once its workgroups (tiles x K splits when a slab is available) cover most of the
+// chip; below that the 64 x 64 weight-streaming kernel is faster (measured: M = 256 x N = 2048 14 vs 25 us).
+bool gemm_big_applicable(const GemmArgs& a, bool may_split) {
     static const int min_rows = [] { const char* e = getenv("LCMHIP_BIG_MIN_ROWS"); return e ? atoi(e) : 256; }();
     const int wrows = a.epilogue == LCMHIP_EPI_SWIGLU ? 2 * a.N : a.N;
-    return a.dtype == LCMHIP_BF16 && a.M >= min_rows && a.K % 64 == 0 && wrows % kBN == 0 && a.lda % 8 == 0;
+    if (!(a.dtype == LCMHIP_BF16 && a.M >= min_rows && a.K % 64 == 0 && wrows % kBN == 0 && a.lda % 8 == 0)) return false;
+    const int tiles = (wrows / kBN) * ((a.M + kBM - 1) / kBM);
+    const int s = may_split ? gemm_big_splits(a, a.max_splits) : 1;
+    return tiles * s >= 192;
 }
 
 // epi: LCMHIP_EPI_* or EPI_PARTIAL; splits >= 1 (only with EPI_PARTIAL); m_rows: rows the row tiles must cover
@@ -130,15 +145,6 @@ int launch_gemm_big(const GemmArgs& a, int epi, int splits, int m_rows, hipStrea
     }
     LCM_HIP_CHECK(hipGetLastError());
     return LCMHIP_OK;
-}
-
-// K splits for the split-K (slab) form: enough workgroups for the chip, at least 8 K tiles per split
-int gemm_big_splits(const GemmArgs& a, int max_splits) {
-    const int tiles = (a.N / kBN) * ((a.M + kBM - 1) / kBM);
-    const int nk = a.K / 64;
-    int s = 1;
-    while (tiles * s < 256 && nk % (s * 2) == 0 && nk / (s * 2) >= 8 && s * 2 <= (max_splits > 0 ? max_splits : 64)) s *= 2;   // splits divide the K tiles
-    return s;
 }
 
 }  // namespace lcmhip

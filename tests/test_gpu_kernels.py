@@ -24,7 +24,7 @@ def _st(hip):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("rows", [1, 7, 300])
+@pytest.mark.parametrize("rows", [1, 7, 300, 70001])
 def test_normalizer_roundtrip(hip, normalizer, dtype, rows):
     torch.manual_seed(0)
     c, s = normalizer["center"].cuda().to(dtype), normalizer["scale"].cuda().to(dtype)
@@ -59,10 +59,10 @@ def test_normalizer_clip(hip, normalizer):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("kind", ["rms", "standard"])
 @pytest.mark.parametrize("dim", [256, 1024, 2048])
-def test_norm_modulate(hip, dtype, kind, dim):
+@pytest.mark.parametrize("rows", [9, 1501])     # >= 1024 rows without a pending product: one wave per row
+def test_norm_modulate(hip, dtype, kind, dim, rows):
     from oracle.model import norm as oracle_norm
     torch.manual_seed(1)
-    rows = 9
     x = (torch.randn(rows, dim) * 3 + 0.5).cuda()
     w = (1 + 0.1 * torch.randn(dim)).cuda().to(dtype)
     b = (0.1 * torch.randn(dim)).cuda().to(dtype) if kind == "standard" else None
@@ -98,7 +98,7 @@ def test_gemm_epilogues(hip, dtype, M, N, K, split):
     _check_epilogues(hip, dtype, M, N, K, split)
 
 
-@pytest.mark.parametrize("M", [256, 300, 1000])
+@pytest.mark.parametrize("M", [256, 300, 1000, 2000])
 @pytest.mark.parametrize("N,K", [(256, 256), (2048, 2048), (1024, 5632)])
 @pytest.mark.parametrize("split", [False, True])
 def test_gemm_many_rows(hip, M, N, K, split):
@@ -109,8 +109,8 @@ def test_gemm_many_rows(hip, M, N, K, split):
 def test_gemm_many_rows_identity_and_row_map(hip):
     """A = I against an asymmetric integer W (exact in bf16) through the 128 x 128 kernel, plain and scattered
     through a row map into the (slot, head, position, 128) cache layout."""
-    M = K = 512
-    N = 256
+    M = K = 2048
+    N = 2048
     A = torch.eye(M, K).cuda().to(torch.bfloat16)
     W = (torch.arange(N).view(N, 1) % 7 - 3 + 2 * (torch.arange(K).view(1, K) % 5)).float().cuda().to(torch.bfloat16)
     out = torch.empty(M, N, device="cuda")
