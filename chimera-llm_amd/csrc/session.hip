@@ -106,7 +106,8 @@ struct lcmhip_model {
     bool finalized = false;
     const void* center = nullptr;
     const void* scale = nullptr;
-    lcmhip::Lin pre_linear, t_fc1, t_fc2, init_proj, final_proj;
+    lcmhip::Lin pre_linear, t_fc1, t_fc2, init_proj, final_proj, postnet;
+    bool base = false;          // base LCM: frontend -> causal decoder -> postnet, no denoiser tower
     const void* pos_table = nullptr;
     std::vector<lcmhip::CtxLayer> ctx;
     std::vector<lcmhip::DenLayer> den;
@@ -133,6 +134,8 @@ static int get_lin(lcmhip_model* m, const std::string& prefix, int out, int in, 
     }
     return LCMHIP_OK;
 }
+
+static bool has_tensor(const lcmhip_model* m, const std::string& name) { return m->tensors.count(name) != 0; }
 
 static int get_vec(lcmhip_model* m, const std::string& name, int n, const void** p) {
     auto t = m->tensors.find(name);
@@ -250,7 +253,7 @@ static size_t carve(lcmhip_session* s, char* base) {
     s->mod_table = c.take<float>((size_t)s->max_steps * d.denoiser.num_layers * 9 * dm * 4);
     s->uconst = c.take<float>((size_t)d.denoiser.num_layers * dm * 4);
     s->xres = c.take<float>(R * dm * 4);
-    s->f32tmp = c.take<float>(R * std::max(dm, (size_t)d.timestep_freq_dim) * 4);
+    s->f32tmp = c.take<float>(R * std::max(std::max(dm, D), (size_t)d.timestep_freq_dim) * 4);
     s->outp = c.take<float>(2 * B * D * 4);
     s->lat = c.take<float>(B * D * 4);
     s->lat2 = c.take<float>(B * D * 4);
@@ -295,18 +298,23 @@ __global__ void k_slot0_rows(int32_t* slot0_rows, int32_t* slot_map, int n, int 
 template <typename T>
 __global__ __launch_bounds__(128) void k_normalize_gather(const float* __restrict__ x, const T* __restrict__ center,
                                                           const T* __restrict__ scale, T* __restrict__ y, int D,
-                                                          int sc, int s_total, int j0, int apply) {
+                                                          int sc, int s_total, int j0, int apply, float escale) {
     const int r = blockIdx.x;
     const int i = r / sc, jj = r % sc;
     const float* src = x + ((size_t)i * s_total + j0 + jj) * D;
     T* dst = y + (size_t)r * D;
     for (int c = threadIdx.x * 8; c < D; c += blockDim.x * 8) {
-        float v[8], ce[8], sv[8];
+        float v[8];
         load8<float>(src + c, v);
-        load8<T>(center + c, ce);
-        load8<T>(scale + c, sv);
+        if (apply) {
+            float ce[8], sv[8];
+            load8<T>(center + c, ce);
+            load8<T>(scale + c, sv);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) v[t] = apply ? (v[t] - ce[t]) / sv[t] : v[t];
+            for (int t = 0; t < 8; ++t) v[t] = (v[t] - ce[t]) / sv[t];
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] *= escale;     // frontend embedding scale (1 unless scale_embeddings)
         store8<T>(dst + c, v);
     }
 }
@@ -320,6 +328,44 @@ __global__ __launch_bounds__(256) void k_keep_rows(const T* __restrict__ src, fl
         float v[8];
         load8<T>(src + (size_t)r * d + c, v);
         store8<float>(dst + (size_t)rows_idx[r] * d + c, v);
+    }
+}
+
+// Output request of a base-LCM forward: postnet + optional sampling noise + denormalize.
+struct BaseOut {
+    float* out = nullptr;          // (n_active, n_out, D) fp32; n_out = n_tokens if all else 1
+    const float* noise = nullptr;  // like out, or null
+    float temperature = 0.f;
+    int all = 0;
+};
+
+// out[dst] = denormalize(y[r] + temperature * noise[dst]) for the rows of one append chunk
+template <typename T>
+__global__ __launch_bounds__(128) void k_base_out(const float* __restrict__ y, const float* __restrict__ noise,
+                                                  const T* __restrict__ center, const T* __restrict__ scale,
+                                                  float* __restrict__ out, int D, int sc, int n_tokens, int j0, int all,
+                                                  float temperature) {
+    const int r = blockIdx.x;
+    const int i = r / sc, j = j0 + r % sc;
+    if (!all && j != n_tokens - 1) return;
+    const size_t dst = all ? (size_t)i * n_tokens + j : (size_t)i;
+    for (int c = threadIdx.x * 8; c < D; c += blockDim.x * 8) {
+        float v[8];
+        load8<float>(y + (size_t)r * D + c, v);
+        if (noise != nullptr) {
+            float z[8];
+            load8<float>(noise + dst * D + c, z);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] += temperature * z[t];
+        }
+        if (center != nullptr) {
+            float ce[8], sv[8];
+            load8<T>(center + c, ce);
+            load8<T>(scale + c, sv);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = v[t] * sv[t] + ce[t];
+        }
+        store8<float>(out + dst * D + c, v);
     }
 }
 
@@ -419,11 +465,17 @@ int lcmhip_model_create(const lcmhip_model_desc* desc, lcmhip_model** out) {
     LCM_REQUIRE(desc->model_dim % 256 == 0 && desc->model_dim <= 8192, "model_create: model_dim");
     LCM_REQUIRE(desc->timestep_freq_dim % 64 == 0 && desc->timestep_freq_dim > 0, "model_create: timestep_freq_dim");
     LCM_TRY(check_tower(desc->context, desc->model_dim, "context"));
-    LCM_TRY(check_tower(desc->denoiser, desc->model_dim, "denoiser"));
-    if (desc->denoiser.pos_kind != LCMHIP_POS_NONE)
-        return fail(LCMHIP_ERR_UNSUPPORTED, "denoiser positional encoders are not implemented (reference archs use none)");
+    const bool base = desc->denoiser.num_layers == 0;   // base LCM: no denoiser tower
+    if (!base) {
+        LCM_TRY(check_tower(desc->denoiser, desc->model_dim, "denoiser"));
+        if (desc->denoiser.pos_kind != LCMHIP_POS_NONE)
+            return fail(LCMHIP_ERR_UNSUPPORTED, "denoiser positional encoders are not implemented (reference archs use none)");
+    }
+    LCM_REQUIRE(desc->embed_scale >= 0.f, "model_create: embed_scale");
     auto* m = new lcmhip_model();
     m->desc = *desc;
+    m->base = base;
+    if (m->desc.embed_scale == 0.f) m->desc.embed_scale = 1.f;
     *out = m;
     return LCMHIP_OK;
 }
@@ -445,27 +497,40 @@ int lcmhip_model_finalize(lcmhip_model* m) {
     LCM_REQUIRE(m, "finalize: null model");
     const lcmhip_model_desc& d = m->desc;
     const int dm = d.model_dim, D = d.sonar_dim;
-    LCM_TRY(get_vec(m, "sonar_normalizer.center", D, &m->center));
-    LCM_TRY(get_vec(m, "sonar_normalizer.scale", D, &m->scale));
-    LCM_TRY(get_lin(m, "encoder_frontend.pre_linear", dm, D, true, &m->pre_linear));
+    // tensor names: two-tower = lcm/models/two_tower_diffusion_lcm/builder.py:104-121, base = base_lcm/builder.py:84-88
+    const std::string fe = m->base ? "frontend" : "encoder_frontend";
+    const std::string dec = m->base ? "lcm" : "context_encoder";
+    const std::string nrm = m->base ? "frontend.sonar_normalizer" : "sonar_normalizer";
+    m->center = m->scale = nullptr;
+    if (!m->base || has_tensor(m, nrm + ".center")) {   // a base LCM may have no normalizer (abstract_lcm/builder.py:92-101)
+        LCM_TRY(get_vec(m, nrm + ".center", D, &m->center));
+        LCM_TRY(get_vec(m, nrm + ".scale", D, &m->scale));
+    }
+    LCM_TRY(get_lin(m, fe + ".pre_linear", dm, D, !m->base || has_tensor(m, fe + ".pre_linear.bias"), &m->pre_linear));
     m->pos_table = nullptr;
     if (d.context.pos_kind == LCMHIP_POS_LEARNED) {
-        auto t = m->tensors.find("encoder_frontend.pos_encoder.weight");
-        if (t == m->tensors.end()) return fail(LCMHIP_ERR_STATE, "missing weight: encoder_frontend.pos_encoder.weight");
+        auto t = m->tensors.find(fe + ".pos_encoder.weight");
+        if (t == m->tensors.end()) return fail(LCMHIP_ERR_STATE, "missing weight: " + fe + ".pos_encoder.weight");
         LCM_REQUIRE(t->second.shape.size() == 2 && t->second.shape[0] >= d.max_seq_len && t->second.shape[1] == dm,
-                    "bad shape for encoder_frontend.pos_encoder.weight");
+                    "bad shape for " + fe + ".pos_encoder.weight");
         m->pos_table = t->second.ptr;
     }
     m->ctx.assign(d.context.num_layers, CtxLayer{});
     for (int i = 0; i < d.context.num_layers; ++i) {
-        const std::string p = "context_encoder.layers." + std::to_string(i);
+        const std::string p = dec + ".layers." + std::to_string(i);
         CtxLayer& L = m->ctx[i];
         LCM_TRY(get_norm(m, p + ".self_attn_layer_norm", dm, d.context.norm_kind, &L.sa_norm));
         LCM_TRY(get_norm(m, p + ".ffn_layer_norm", dm, d.context.norm_kind, &L.ffn_norm));
         LCM_TRY(get_attn(m, p + ".self_attn", dm, d.context.out_proj_bias != 0, &L.sa));
         LCM_TRY(get_ffn(m, p + ".ffn", dm, d.context, &L.ffn));
     }
-    LCM_TRY(get_norm(m, "context_encoder.layer_norm", dm, d.context.norm_kind, &m->ctx_final));
+    LCM_TRY(get_norm(m, dec + ".layer_norm", dm, d.context.norm_kind, &m->ctx_final));
+    m->den.clear();
+    if (m->base) {
+        LCM_TRY(get_lin(m, "postnet.fc", D, dm, has_tensor(m, "postnet.fc.bias"), &m->postnet));
+        m->finalized = true;
+        return LCMHIP_OK;
+    }
     LCM_TRY(get_lin(m, "denoiser.embed_time.fc1", dm, d.timestep_freq_dim, true, &m->t_fc1));
     LCM_TRY(get_lin(m, "denoiser.embed_time.fc2", dm, dm, true, &m->t_fc2));
     LCM_TRY(get_lin(m, "denoiser.initial_proj.fc", dm, D, true, &m->init_proj));
@@ -603,6 +668,7 @@ int lcmhip_session_set_schedule(lcmhip_session* s, const int32_t* timesteps, int
                                 const float* alphas_cumprod, int32_t num_train_steps, float final_alpha_cumprod,
                                 int32_t step_ratio, const lcmhip_denoise_params* params, void* stream) {
     LCM_REQUIRE(s && timesteps && alphas_cumprod && params, "set_schedule: null argument");
+    LCM_REQUIRE(!s->model->base, "set_schedule: a base LCM has no diffusion schedule");
     LCM_REQUIRE(n_steps >= 1 && n_steps <= s->max_steps, "set_schedule: more steps than the session was sized for");
     if (params->ddim_eta != 0.f)
         return fail(LCMHIP_ERR_UNSUPPORTED, "ddim_eta != 0 (stochastic DDIM) is not implemented");
@@ -672,7 +738,8 @@ int lcmhip_session_set_schedule(lcmhip_session* s, const int32_t* timesteps, int
 }
 
 // ------------------------------------------------------------------------------------------------ contextualizer
-int lcmhip_context_append(lcmhip_session* s, const float* x, int32_t n_tokens, int32_t normalized, void* stream) {
+static int append_impl(lcmhip_session* s, const float* x, int32_t n_tokens, int32_t normalized, void* stream,
+                       const BaseOut* bo) {
     LCM_REQUIRE(s && x, "context_append: null argument");
     LCM_REQUIRE(s->n_active >= 1, "context_append: call session_reset first");
     LCM_REQUIRE(n_tokens >= 1 && s->ctx_len + n_tokens <= s->cap, "context_append: context exceeds the session's max_ctx");
@@ -697,10 +764,10 @@ int lcmhip_context_append(lcmhip_session* s, const float* x, int32_t n_tokens, i
             ProfScope ps(&s->prof, "ctx.normalize", R * (double)D * (4.0 + es), 0.0, st);
             if (d.dtype == LCMHIP_BF16)
                 hipLaunchKernelGGL((k_normalize_gather<bf16_t>), dim3(R), dim3(128), 0, st, x, (const bf16_t*)m->center,
-                                   (const bf16_t*)m->scale, (bf16_t*)s->act_in, D, sc, n_tokens, j0, normalized ? 0 : 1);
+                                   (const bf16_t*)m->scale, (bf16_t*)s->act_in, D, sc, n_tokens, j0, (normalized || !m->center) ? 0 : 1, d.embed_scale);
             else
                 hipLaunchKernelGGL((k_normalize_gather<float>), dim3(R), dim3(128), 0, st, x, (const float*)m->center,
-                                   (const float*)m->scale, (float*)s->act_in, D, sc, n_tokens, j0, normalized ? 0 : 1);
+                                   (const float*)m->scale, (float*)s->act_in, D, sc, n_tokens, j0, (normalized || !m->center) ? 0 : 1, d.embed_scale);
             LCM_HIP_CHECK(hipGetLastError());
         }
         LCM_TRY(gemm(s, "ctx.frontend", s->act_in, D, m->pre_linear, nullptr, nullptr, s->xres, dm, R, LCMHIP_EPI_STORE_F32, st));
@@ -742,9 +809,36 @@ int lcmhip_context_append(lcmhip_session* s, const float* x, int32_t n_tokens, i
                 hipLaunchKernelGGL((k_keep_rows<float>), dim3(R), dim3(256), 0, st, (const float*)s->act_a, s->kept_ctx, s->self_rows, dm);
             LCM_HIP_CHECK(hipGetLastError());
         }
+        // base LCM: postnet on the decoder output (projection.py:80-86), sampling noise, denormalize
+        if (bo && bo->out && (bo->all || j0 + sc == n_tokens)) {
+            LCM_TRY(gemm(s, "base.postnet", s->act_a, dm, m->postnet, nullptr, nullptr, s->f32tmp, D, R, LCMHIP_EPI_STORE_F32, st));
+            ProfScope ps(&s->prof, "base.out", R * (double)D * 8.0, 0.0, st);
+            if (d.dtype == LCMHIP_BF16)
+                hipLaunchKernelGGL((k_base_out<bf16_t>), dim3(R), dim3(128), 0, st, s->f32tmp, bo->noise, (const bf16_t*)m->center,
+                                   (const bf16_t*)m->scale, bo->out, D, sc, n_tokens, j0, bo->all, bo->temperature);
+            else
+                hipLaunchKernelGGL((k_base_out<float>), dim3(R), dim3(128), 0, st, s->f32tmp, bo->noise, (const float*)m->center,
+                                   (const float*)m->scale, bo->out, D, sc, n_tokens, j0, bo->all, bo->temperature);
+            LCM_HIP_CHECK(hipGetLastError());
+        }
     }
     s->ctx_len += n_tokens;
     return LCMHIP_OK;
+}
+
+int lcmhip_context_append(lcmhip_session* s, const float* x, int32_t n_tokens, int32_t normalized, void* stream) {
+    return append_impl(s, x, n_tokens, normalized, stream, nullptr);
+}
+
+int lcmhip_base_forward(lcmhip_session* s, const float* x, int32_t n_tokens, int32_t normalized, const float* noise,
+                        float temperature, int32_t all_positions, float* out, void* stream) {
+    LCM_REQUIRE(s && s->model->base, "base_forward: the model is not a base LCM (it has a denoiser tower)");
+    BaseOut bo;
+    bo.out = out;
+    bo.noise = (noise != nullptr && temperature > 0.f) ? noise : nullptr;
+    bo.temperature = temperature;
+    bo.all = all_positions ? 1 : 0;
+    return append_impl(s, x, n_tokens, normalized, stream, &bo);
 }
 
 int lcmhip_session_read_context(lcmhip_session* s, int32_t row, float* out, void* stream) {
@@ -760,6 +854,7 @@ int lcmhip_session_read_context(lcmhip_session* s, int32_t row, float* out, void
 // ------------------------------------------------------------------------------------------------ denoising loop
 int lcmhip_denoise(lcmhip_session* s, const float* noise, float* out, float* latents_trace, void* stream) {
     LCM_REQUIRE(s && noise && out, "denoise: null argument");
+    LCM_REQUIRE(!s->model->base, "denoise: a base LCM has no denoiser (use lcmhip_base_forward)");
     if (!s->have_schedule) return fail(LCMHIP_ERR_STATE, "denoise: call session_set_schedule first");
     LCM_REQUIRE(s->n_active >= 1 && s->ctx_len >= 1, "denoise: empty context (append at least one position first)");
     hipStream_t st = static_cast<hipStream_t>(stream);

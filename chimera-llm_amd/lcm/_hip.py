@@ -43,7 +43,7 @@ class TowerDesc(C.Structure):
 class ModelDesc(C.Structure):
     _fields_ = [("sonar_dim", C.c_int32), ("model_dim", C.c_int32), ("max_seq_len", C.c_int32),
                 ("timestep_freq_dim", C.c_int32), ("dtype", C.c_int32), ("norm_eps", C.c_float),
-                ("context", TowerDesc), ("denoiser", TowerDesc)]
+                ("context", TowerDesc), ("denoiser", TowerDesc), ("embed_scale", C.c_float)]
 
 
 class DenoiseParams(C.Structure):
@@ -79,6 +79,7 @@ def _load() -> C.CDLL:
                                         C.POINTER(DenoiseParams), vp],
         "lcmhip_session_reset": [vp, i32, vp],
         "lcmhip_context_append": [vp, vp, i32, i32, vp],
+        "lcmhip_base_forward": [vp, vp, i32, i32, vp, f32, i32, vp, vp],
         "lcmhip_denoise": [vp, vp, vp, vp, vp],
         "lcmhip_session_reorder": [vp, C.POINTER(i32), i32, vp],
         "lcmhip_session_context_len": [vp],

@@ -191,6 +191,25 @@ class DeviceSession:
         assert x32.dim() == 3 and x32.shape[0] == self.num_active, (tuple(x32.shape), self.num_active)
         _hip.check(_hip.lib.lcmhip_context_append(self._h, _hip.ptr(x32), x32.shape[1], int(normalized), self._stream()))
 
+    def base_forward(self, x: Tensor, *, normalized: bool, noise: Optional[Tensor], temperature: float,
+                     all_positions: bool, want_output: bool = True) -> Optional[Tensor]:
+        """Base LCM: appends the s positions of x (n_active, s, D) and returns the predictions, fp32, for every
+        position (n_active, s, D) or for the last one (n_active, D); None when only the cache is wanted."""
+        _hip.require_gpu(x, "input embeddings")
+        x32 = x.float().contiguous()
+        assert x32.dim() == 3 and x32.shape[0] == self.num_active, (tuple(x32.shape), self.num_active)
+        out = None
+        if want_output:
+            shape = x32.shape if all_positions else (x32.shape[0], x32.shape[2])
+            out = torch.empty(shape, dtype=torch.float32, device=x32.device)
+        nz = None
+        if noise is not None and want_output:
+            nz = noise.float().contiguous()
+            assert nz.numel() == out.numel(), "noise must have the shape of the output"
+        _hip.check(_hip.lib.lcmhip_base_forward(self._h, _hip.ptr(x32), x32.shape[1], int(normalized), _hip.ptr(nz),
+                                                float(temperature), int(all_positions), _hip.ptr(out), self._stream()))
+        return out
+
     def denoise(self, noise: Tensor, trace: Optional[Tensor] = None) -> Tensor:
         """noise: (n_active, D) N(0, 1) draws -> next sentence embedding (n_active, D) fp32."""
         _hip.require_gpu(noise, "noise")

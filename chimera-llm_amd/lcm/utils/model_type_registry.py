@@ -23,7 +23,10 @@ def _register_defaults() -> None:
     from lcm.models.sonar_normalizer.loader import load_sonar_normalizer_model
     from lcm.models.two_tower_diffusion_lcm.loader import load_two_tower_diffusion_lcm_model
 
+    from lcm.models.base_lcm.loader import load_base_lcm_model
+
     lcm_model_type_registry.register("two_tower_diffusion_lcm", load_two_tower_diffusion_lcm_model)
+    lcm_model_type_registry.register("base_lcm", load_base_lcm_model)
     lcm_model_type_registry.register("sonar_normalizer", load_sonar_normalizer_model)
 
 

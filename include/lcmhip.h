@@ -71,8 +71,10 @@ typedef struct {
     int32_t timestep_freq_dim; /* 256, lcm/nn/timestep_encoder.py:28 */
     int32_t dtype;             /* LCMHIP_F32 or LCMHIP_BF16: dtype of every bound weight and of GEMM operands */
     float norm_eps;
-    lcmhip_tower_desc context;
-    lcmhip_tower_desc denoiser;
+    lcmhip_tower_desc context;   /* two-tower: the contextualizer; base LCM: the causal decoder ("lcm") */
+    lcmhip_tower_desc denoiser;  /* num_layers == 0 selects the base LCM (lcm/models/base_lcm/builder.py:64-124):
+                                    frontend -> causal decoder -> postnet, tensor names frontend.*, lcm.*, postnet.fc.* */
+    float embed_scale;           /* frontend input scale, lcm/models/base_lcm/frontend.py:91, 170; 0 means 1 */
 } lcmhip_model_desc;
 
 /* Options of DiffusionLCMGeneratorOptions that reach the arithmetic
@@ -156,6 +158,19 @@ int lcmhip_session_reset(lcmhip_session* s, int32_t n_docs, void* stream);
  * while staging), already normalized otherwise (what TwoTowerDiffusionLCModel.encode receives). */
 int lcmhip_context_append(lcmhip_session* s, const float* x, int32_t n_tokens, int32_t normalized,
                           void* stream);
+
+/* Base LCM only.  Replaces BaseLCModel.predict_next_sentence (lcm/models/base_lcm/builder.py:126-167):
+ * SonarNormalizer.normalize (skipped when `normalized` != 0 or the model has no normalizer), LCMFrontend.forward
+ * (base_lcm/frontend.py:154-183), the KV-cached causal decoder (lcm/nn/transformer/decoder.py:131-176), the
+ * postnet Projection (lcm/nn/projection.py:80-86), `+ temperature * noise` when `noise` is not NULL and
+ * temperature > 0 (builder.py:158-160, with host-supplied N(0,1) draws instead of randn_like), and denormalize.
+ * `x` is (n_active, n_tokens, sonar_dim) fp32: the next n_tokens positions of every active document, appended to
+ * the session's KV cache.  `out` receives (n_active, n_tokens, sonar_dim) fp32 when all_positions != 0, else the
+ * prediction after the last position only, (n_active, sonar_dim); `noise` has the shape of `out`.
+ * out == NULL only fills the cache (the generator's prefill, lcm/inference/lcm/generator.py:226-246). */
+int lcmhip_base_forward(lcmhip_session* s, const float* x, int32_t n_tokens, int32_t normalized,
+                        const float* noise, float temperature, int32_t all_positions, float* out,
+                        void* stream);
 
 /* Replaces the sampling loop of predict_next_sentence[_with_cf_guidance] (builder.py:299-338,
  * 366-461): sample_initial_noise_vectors with host-supplied N(0,1) `noise` (n_active, sonar_dim)

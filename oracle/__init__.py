@@ -16,8 +16,8 @@ identities of the algorithm, and (c) the one data fixture the reference ships
 Each function cites the reference file:line it follows (paths relative to the reference root).
 """
 
-from .archs import ArchConfig, get_arch, ARCHS  # noqa: F401
+from .archs import ArchConfig, get_arch, ARCHS, BaseArchConfig, get_base_arch, BASE_ARCHS  # noqa: F401
 from .weights import init_state_dict, load_dummy_normalizer  # noqa: F401
 from .scheduler import DDIMSchedule  # noqa: F401
-from .model import OracleTwoTower  # noqa: F401
+from .model import OracleTwoTower, OracleBaseLCM  # noqa: F401
 from .generator import OracleGenerator, GenOptions  # noqa: F401

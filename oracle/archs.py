@@ -91,6 +91,53 @@ def _mini() -> ArchConfig:
                       trained_with_cf_guidance=True)
 
 
+@dataclass
+class BaseArchConfig:
+    """lcm/models/base_lcm/builder.py:37-57 (BaseLCModelConfig): frontend -> causal decoder -> postnet."""
+    name: str = "toy_base_lcm"
+    sonar_dim: int = 1024
+    model_dim: int = 1024
+    max_seq_len: int = 2048
+    norm_eps: float = 1e-5
+    lcm: TowerConfig = field(default_factory=TowerConfig)
+    pre_linear_bias: bool = True           # base_lcm/frontend.py:30
+    postnet_bias: bool = True              # lcm/nn/projection.py:28
+    scale_embeddings: bool = False         # base_lcm/frontend.py:35, 91
+    sonar_normalizer_name: str = None      # abstract_lcm/builder.py:33: no normalizer unless named
+
+
+def _toy_base() -> BaseArchConfig:
+    # lcm/models/base_lcm/archs.py:17-21: defaults with a 2-layer decoder.
+    return BaseArchConfig()
+
+
+def _base_1_6b() -> BaseArchConfig:
+    """`base_lcm_1_6B` is NOT defined in the reference fork (its base_lcm/archs.py holds only the toy and an
+    unrelated arch); this is the upstream-LCM-style reconstruction used for the "base_lcm 1.6B forward" benchmark
+    shape: d = 2048, 32 layers, 16 heads, RoPE, SwiGLU (8192 -> 5632), RMSNorm, output-projection bias."""
+    t = TowerConfig(num_layers=32, num_heads=16, ffn_inner_dim=8192, use_swiglu=True, norm="rms", pos="rope",
+                    out_proj_bias=True)
+    return BaseArchConfig(name="base_lcm_1_6B", model_dim=2048, max_seq_len=4096, lcm=t,
+                          sonar_normalizer_name="dummy_sonar_normalizer")
+
+
+def _mini_base() -> BaseArchConfig:
+    """Not a reference arch: 1.6B-style blocks small enough for unit tests."""
+    t = TowerConfig(num_layers=3, num_heads=2, ffn_inner_dim=1024, use_swiglu=True, norm="rms", pos="rope",
+                    out_proj_bias=True)
+    return BaseArchConfig(name="mini_base_lcm", model_dim=256, max_seq_len=512, lcm=t,
+                          sonar_normalizer_name="dummy_sonar_normalizer")
+
+
+BASE_ARCHS = {"toy_base_lcm": _toy_base, "base_lcm_1_6B": _base_1_6b, "mini_base_lcm": _mini_base}
+
+
+def get_base_arch(name: str) -> BaseArchConfig:
+    cfg = BASE_ARCHS[name]()
+    cfg.name = name
+    return cfg
+
+
 ARCHS = {
     "toy_two_tower_diffusion_lcm": _toy,
     "two_tower_diffusion_lcm_1_6B": lambda: _big("two_tower_diffusion_lcm_1_6B", 2048, 16, 13),

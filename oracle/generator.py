@@ -14,7 +14,7 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor
 
-from .model import KVCache, OracleTwoTower
+from .model import OracleBaseLCM, KVCache, OracleTwoTower
 
 
 @dataclass
@@ -23,6 +23,7 @@ class GenOptions:
     min_seq_len: int = 1
     eos_threshold: Optional[float] = 0.9
     stop_on_repetition_cosine_threshold: Optional[float] = None
+    sample_latent_variable: bool = True
     include_eos_token: bool = False
     trim_hypotheses: bool = False
     seed: Optional[int] = None
@@ -57,10 +58,11 @@ class OracleGenerator:
     @torch.inference_mode()
     def __call__(self, seqs_in: Tensor, prompt_lens: Optional[Tensor] = None, max_gen_len: Optional[int] = None,
                  min_gen_len: Optional[int] = None, noise: Optional[Tensor] = None,
-                 trace: Optional[list] = None) -> List[List[Hyp]]:
+                 trace: Optional[list] = None, temperature: float = 0.0) -> List[List[Hyp]]:
         """seqs_in (B,P,D) padded prompts; prompt_lens (B,) or None; noise (steps,B,D) consumed as
         noise[step_nr - min_prompt_len, original document]."""
         opt, model = self.options, self.model
+        self.temperature = temperature if temperature != 0.0 else opt.lcm_temperature   # lcm/generator.py:174-179
         B, P_max, D = seqs_in.shape
         if prompt_lens is None:
             P_min, pmask = P_max, None
@@ -83,11 +85,14 @@ class OracleGenerator:
 
         # prefill (generator.py:222-259): everything but the last common prompt position
         prefill_len = P_min - 1
+        base = isinstance(model, OracleBaseLCM)     # lcm/inference/lcm/generator.py:226-246 (same prefill rule)
+        context = None if base else torch.empty(B, 0, model.model_dim)
         if prefill_len > 0:
-            context = model.encode(model.normalize(seqs[:, :prefill_len]), cache)
+            if base:
+                model.predict(seqs[:, :prefill_len], cache)                   # output discarded, cache filled
+            else:
+                context = model.encode(model.normalize(seqs[:, :prefill_len]), cache)
             cache.increment_step_nr(prefill_len)
-        else:
-            context = torch.empty(B, 0, model.model_dim)
 
         for step_nr in range(P_min, total):
             n_act = seqs.shape[0]
@@ -95,8 +100,14 @@ class OracleGenerator:
                 nz = noise[step_nr - P_min].index_select(0, sample_idx).unsqueeze(1)
             else:
                 nz = torch.randn(n_act, 1, D)
-            out, context = model.predict_next_sentence(seqs[:, step_nr - 1:step_nr], context, cache, nz,
-                                                       trace=trace)
+            if base:
+                # lcm/inference/lcm/generator.py:248-286: one position through the cached decoder
+                out = model.predict(seqs[:, step_nr - 1:step_nr], cache, nz, sample=opt.sample_latent_variable,
+                                    temperature=self.temperature)
+                cache.increment_step_nr()
+            else:
+                out, context = model.predict_next_sentence(seqs[:, step_nr - 1:step_nr], context, cache, nz,
+                                                           trace=trace)
             last = out[:, -1]
 
             # ---- finalize_step (generator.py:305-423)
@@ -135,7 +146,8 @@ class OracleGenerator:
                 break
             # ---- reorder_state (generator.py:442-466)
             cache.reorder(active)
-            context = context.index_select(0, active)
+            if context is not None:
+                context = context.index_select(0, active)
             seqs = seqs.index_select(0, active)
             sample_idx = sample_idx.index_select(0, active)
             step_scores = step_scores.index_select(0, active)

@@ -170,22 +170,24 @@ class OracleTwoTower:
         return linear(F.relu(linear(x, sd, prefix + ".inner_proj")), sd, prefix + ".output_proj")
 
     # -- contextualizer (builder.py:161-191)
-    def encode(self, x_norm: Tensor, cache: Optional[KVCache] = None) -> Tensor:
-        cfg, sd, tc = self.cfg, self.sd, self.cfg.context
+    def encode(self, x_norm: Tensor, cache: Optional[KVCache] = None, *, frontend: str = "encoder_frontend",
+               decoder: str = "context_encoder", tc: Optional[TowerConfig] = None) -> Tensor:
+        cfg, sd = self.cfg, self.sd
+        tc = tc or self.cfg.context
         S = x_norm.shape[1]
         start = cache.step_nr if cache is not None else 0
-        x = linear(x_norm, sd, "encoder_frontend.pre_linear")                # frontend.py:139
+        x = linear(x_norm, sd, frontend + ".pre_linear")                     # frontend.py:139
         if tc.pos == "learned":                                             # frontend.py:141-147
-            x = x + sd["encoder_frontend.pos_encoder.weight"][start:start + S]
+            x = x + sd[frontend + ".pos_encoder.weight"][start:start + S]
         mask = causal_mask(S, start + S)                                     # decoder.py:145-152
         for i in range(tc.num_layers):
-            p = f"context_encoder.layers.{i}"
+            p = f"{decoder}.layers.{i}"
             h = norm(x, sd, p + ".self_attn_layer_norm", tc.norm, cfg.norm_eps)
             x = x + self._mha(p + ".self_attn", tc, h, h, mask=mask, cache=cache, layer=i,
                               use_rope=(tc.pos == "rope"))                   # decoder.py:55-88
             h = norm(x, sd, p + ".ffn_layer_norm", tc.norm, cfg.norm_eps)
             x = x + self._ffn(p + ".ffn", tc, h)
-        return norm(x, sd, "context_encoder.layer_norm", tc.norm, cfg.norm_eps)   # decoder.py:170-171
+        return norm(x, sd, decoder + ".layer_norm", tc.norm, cfg.norm_eps)        # decoder.py:170-171
 
     # -- timestep embedding (lcm/nn/timestep_encoder.py:72-122)
     def embed_time(self, timesteps: Tensor) -> Tensor:
@@ -303,3 +305,43 @@ class OracleTwoTower:
         # the reference returns the doubled context; the generator keeps only the conditional half
         # (generator.py:442-448), which is what is returned here.
         return self.denormalize(x0), context
+
+
+class OracleBaseLCM(OracleTwoTower):
+    """Base (MSE) LCM: frontend -> causal decoder -> postnet, lcm/models/base_lcm/builder.py:94-167 and
+    base_lcm/frontend.py:154-183.  Reuses the attention / FFN / norm blocks of the two-tower oracle."""
+
+    def __init__(self, cfg, sd: Dict[str, Tensor]):
+        self.cfg = cfg
+        self.sd = sd
+        self.model_dim = cfg.model_dim
+        self.has_normalizer = "frontend.sonar_normalizer.center" in sd
+
+    def prep_for_denoising(self, opt) -> None:   # the generator calls it for diffusion models only
+        pass
+
+    def normalize(self, x: Tensor) -> Tensor:
+        if not self.has_normalizer:
+            return x
+        return (x - self.sd["frontend.sonar_normalizer.center"]) / self.sd["frontend.sonar_normalizer.scale"]
+
+    def denormalize(self, x: Tensor) -> Tensor:
+        if not self.has_normalizer:
+            return x
+        return x * self.sd["frontend.sonar_normalizer.scale"] + self.sd["frontend.sonar_normalizer.center"]
+
+    def forward(self, x_norm: Tensor, cache: Optional[KVCache] = None) -> Tensor:
+        """builder.py:94-124 on already-normalized inputs; `embed_scale` per frontend.py:91, 170."""
+        scale = self.cfg.model_dim ** 0.5 if self.cfg.scale_embeddings else 1.0
+        h = self.encode(scale * x_norm, cache, frontend="frontend", decoder="lcm", tc=self.cfg.lcm)
+        return linear(h, self.sd, "postnet.fc")                              # projection.py:80-86
+
+    def predict(self, x: Tensor, cache: Optional[KVCache] = None, noise: Optional[Tensor] = None,
+                sample: bool = False, temperature: float = 1.0) -> Tensor:
+        """predict_next_sentence, builder.py:126-167: normalize, forward, optional N(0, temperature^2) noise on
+        the normalized prediction (host-supplied instead of randn_like), denormalize.  All positions."""
+        y = self.forward(self.normalize(x), cache)
+        if sample and temperature > 0:
+            assert noise is not None, "sampling needs host-supplied noise"
+            y = y + noise * temperature
+        return self.denormalize(y)

@@ -97,6 +97,24 @@ def state_dict_spec(cfg: ArchConfig):
     yield from _tower_shapes("denoiser", d, cfg.denoiser, cross=True, modulator=True)
 
 
+def base_state_dict_spec(cfg):
+    """(name, shape, kind) of a base LCM (module names of lcm/models/base_lcm/builder.py:84-88,
+    base_lcm/frontend.py:96-124, lcm/nn/projection.py:66-69)."""
+    d, D = cfg.model_dim, cfg.sonar_dim
+    if cfg.sonar_normalizer_name is not None:
+        yield "frontend.sonar_normalizer.center", (D,), "normalizer"
+        yield "frontend.sonar_normalizer.scale", (D,), "normalizer"
+    yield "frontend.pre_linear.weight", (d, D), "w"
+    if cfg.pre_linear_bias:
+        yield "frontend.pre_linear.bias", (d,), "b"
+    if cfg.lcm.pos == "learned":
+        yield "frontend.pos_encoder.weight", (cfg.max_seq_len, d), "pos"
+    yield from _tower_shapes("lcm", d, cfg.lcm, cross=False, modulator=False)
+    yield "postnet.fc.weight", (D, d), "w"
+    if cfg.postnet_bias:
+        yield "postnet.fc.bias", (D,), "b"
+
+
 def num_parameters(cfg: ArchConfig) -> int:
     n = 0
     for name, shape, kind in state_dict_spec(cfg):
@@ -123,7 +141,8 @@ def init_state_dict(cfg: ArchConfig, seed: int = 0, *, w_std: float = 0.02, b_st
     """
     normalizer = normalizer or load_dummy_normalizer()
     sd: Dict[str, torch.Tensor] = {}
-    for name, shape, kind in state_dict_spec(cfg):
+    spec = base_state_dict_spec(cfg) if hasattr(cfg, "lcm") else state_dict_spec(cfg)
+    for name, shape, kind in spec:
         if kind == "normalizer":
             sd[name] = normalizer[name.split(".")[-1]].clone()
         elif kind == "w":

@@ -1,0 +1,115 @@
+"""Parity of the base (MSE) LCM on the HIP path against the CPU oracle: forward over whole sequences
+(BASELINE config 2's shape, reduced) and sentence-by-sentence generation with the KV cache.
+
+Tolerances as for the two-tower path: fp32 max-abs <= 1e-3 (normalizer units) and cosine >= 0.9999; bf16
+cosine >= 0.999.  The reference's own invariants for this generator are restated on the HIP path:
+KV cache on == off (tests/units/inference/test_base_lcm_kv_caching.py, atol 1e-3) and batch == singles
+(tests/units/inference/test_base_lcm_batched_inference.py).
+"""
+
+import pytest
+import torch
+
+import oracle
+from parity_utils import (base_config, compare, compare_raw, make_base_problem, run_hip_base, run_oracle_base)
+
+pytestmark = pytest.mark.gpu
+
+FP32_MAX_ABS, FP32_COS, BF16_COS = 1e-3, 0.9999, 0.999
+OPTS = dict(eos_threshold=None)
+
+
+def _norm_sd(sd):
+    return {"sonar_normalizer.center": sd["frontend.sonar_normalizer.center"],
+            "sonar_normalizer.scale": sd["frontend.sonar_normalizer.scale"]}
+
+
+@pytest.mark.parametrize("sample", [True, False])
+def test_toy_base_generation_fp32(sample):
+    """toy_base_lcm (LayerNorm, learned positions, ReLU FFN, no normalizer): 4 docs x (3 + 5)."""
+    arch = "toy_base_lcm"
+    cfg, sd, x, nz = make_base_problem(arch, 4, 3, 5)
+    opts = dict(OPTS, sample_latent_variable=sample, lcm_temperature=0.3)
+    ref = run_oracle_base(cfg, sd, x, nz, 5, opts)
+    out, _ = run_hip_base(arch, sd, x, nz, 5, opts)
+    worst, cos = compare_raw(out.hypotheses, ref, start=3)
+    assert worst <= FP32_MAX_ABS and cos >= FP32_COS, (worst, cos)
+    assert all(h[0].seq.shape == (8, 1024) for h in out.hypotheses)
+
+
+def test_mini_base_generation_fp32_and_bf16():
+    """1.6B-style blocks (RMSNorm, RoPE, SwiGLU, out-proj bias, normalizer)."""
+    arch = "mini_base_lcm"
+    cfg, sd, x, nz = make_base_problem(arch, 5, 4, 6)
+    opts = dict(OPTS, lcm_temperature=0.5)
+    ref = run_oracle_base(cfg, sd, x, nz, 6, opts)
+    out, _ = run_hip_base(arch, sd, x, nz, 6, opts)
+    worst, cos = compare(out.hypotheses, ref, _norm_sd(sd), start=4)
+    assert worst <= FP32_MAX_ABS and cos >= FP32_COS, (worst, cos)
+    sd16 = {k: v.bfloat16().float() for k, v in sd.items()}
+    ref16 = run_oracle_base(cfg, sd16, x.bfloat16().float(), nz, 6, opts)
+    out16, _ = run_hip_base(arch, sd, x, nz, 6, opts, dtype=torch.bfloat16)
+    worst, cos = compare(out16.hypotheses, ref16, _norm_sd(sd16), start=4)
+    assert cos >= BF16_COS, (worst, cos)
+
+
+@pytest.mark.parametrize("arch,B,S", [("toy_base_lcm", 3, 40), ("mini_base_lcm", 6, 200)])
+def test_base_forward_all_positions(arch, B, S):
+    """predict_next_sentence over whole sequences without a cache (the benchmark forward's shape, reduced): rows
+    B * S exceed 256, so the bf16 run goes through the many-row matrix-core GEMM."""
+    from lcm.datasets.batch import EmbeddingsBatch
+    from lcm.models.base_lcm import create_base_lcm_model
+    cfg, sd, x, _ = make_base_problem(arch, B, S, 0)
+    ref = oracle.OracleBaseLCM(cfg, sd).predict(x)
+    model = create_base_lcm_model(base_config(arch), device="cuda:0", dtype=torch.float32)
+    model.load_state_dict(sd)
+    out = model.predict_next_sentence(EmbeddingsBatch(x.cuda(), None)).seqs.cpu()
+    scale = ref.abs().max()
+    assert (out - ref).abs().max() <= 2e-4 * scale
+    assert torch.nn.functional.cosine_similarity(out, ref, dim=-1).min() >= FP32_COS
+    if arch == "mini_base_lcm":
+        sd16 = {k: v.bfloat16().float() for k, v in sd.items()}
+        ref16 = oracle.OracleBaseLCM(cfg, sd16).predict(x.bfloat16().float())
+        m16 = create_base_lcm_model(base_config(arch), device="cuda:0", dtype=torch.bfloat16)
+        m16.load_state_dict(sd)
+        out16 = m16.predict_next_sentence(EmbeddingsBatch(x.cuda().bfloat16(), None)).seqs.cpu()
+        c, s = sd16["frontend.sonar_normalizer.center"], sd16["frontend.sonar_normalizer.scale"]
+        cos = torch.nn.functional.cosine_similarity((out16 - c) / s, (ref16 - c) / s, dim=-1)
+        assert cos.min() >= BF16_COS, float(cos.min())
+
+
+def test_kv_cache_on_equals_off():
+    arch = "mini_base_lcm"
+    cfg, sd, x, nz = make_base_problem(arch, 3, 4, 4)
+    opts = dict(OPTS, lcm_temperature=0.5)
+    a, model = run_hip_base(arch, sd, x, nz, 4, opts)
+    b, _ = run_hip_base(arch, sd, x, nz, 4, opts, model=model, disable_cache=True)
+    for ha, hb in zip(a.hypotheses, b.hypotheses):
+        assert torch.allclose(ha[0].seq, hb[0].seq, atol=1e-3, rtol=1e-3)
+
+
+def test_batch_equals_singles_and_ragged_eos():
+    arch = "mini_base_lcm"
+    lens = [2, 4, 3]
+    cfg, sd, x, nz = make_base_problem(arch, 3, 4, 4, prompt_lens=lens)
+    opts = dict(OPTS, lcm_temperature=0.5)
+    ref = run_oracle_base(cfg, sd, x, nz, 4, opts, prompt_lens=lens)
+    out, model = run_hip_base(arch, sd, x, nz, 4, opts, prompt_lens=lens)
+    for i, n in enumerate(lens):
+        assert out.hypotheses[i][0].seq.shape[0] == n + 4 == ref[i][0].seq.shape[0]
+    worst, cos = compare(out.hypotheses, ref, _norm_sd(sd))
+    assert worst <= FP32_MAX_ABS and cos >= FP32_COS, (worst, cos)
+    # EOS: stop document 1 at its second generated sentence
+    eos = ref[1][0].seq[5].clone()
+    opts_eos = dict(opts, eos_threshold=0.999, trim_hypotheses=True)
+    ref_e = run_oracle_base(cfg, sd, x, nz, 4, opts_eos, prompt_lens=lens, eos_vec=eos)
+    out_e, _ = run_hip_base(arch, sd, x, nz, 4, opts_eos, prompt_lens=lens, eos_vec=eos, model=model)
+    assert [h[0].seq.shape[0] for h in out_e.hypotheses] == [h[0].seq.shape[0] for h in ref_e]
+    assert ref_e[1][0].seq.shape[0] == 5
+    # a document alone == the same document in the batch (unpadded prompts, noise indexed by document)
+    cfg, sd, x, nz = make_base_problem(arch, 3, 3, 3)
+    full, model = run_hip_base(arch, sd, x, nz, 3, opts)
+    for i in range(3):
+        one, _ = run_hip_base(arch, sd, x[i:i + 1], nz[:, i:i + 1], 3, opts, model=model)
+        a, b = one.hypotheses[0][0].seq, full.hypotheses[i][0].seq
+        assert (a - b).abs().max() <= 1e-6 * max(1.0, float(b.abs().max()))
