@@ -25,7 +25,7 @@ EXPORTS = [
     "lcmhip_last_error", "lcmhip_version",
     "lcmhip_model_create", "lcmhip_model_bind_weight", "lcmhip_model_finalize", "lcmhip_model_destroy",
     "lcmhip_session_workspace_bytes", "lcmhip_session_create", "lcmhip_session_destroy",
-    "lcmhip_session_set_schedule", "lcmhip_session_reset", "lcmhip_context_append", "lcmhip_denoise",
+    "lcmhip_session_set_schedule", "lcmhip_session_reset", "lcmhip_context_append", "lcmhip_base_forward", "lcmhip_denoise",
     "lcmhip_session_reorder", "lcmhip_session_context_len", "lcmhip_session_num_active",
     "lcmhip_session_read_context", "lcmhip_session_profile_enable", "lcmhip_session_profile",
     "lcmhip_normalize", "lcmhip_denormalize", "lcmhip_norm_modulate", "lcmhip_gemm", "lcmhip_gemm_partial",

@@ -199,4 +199,3 @@ def test_1_6b_full_batch_properties():
         single, _ = run_hip(arch, sd, x[i:i + 1], nz[:, i:i + 1], G, opts, dtype=torch.bfloat16, model=model)
         u, v = single.hypotheses[0][0].seq.float()[P:], a.hypotheses[i][0].seq.float()[P:]
         assert torch.nn.functional.cosine_similarity(u, v, dim=-1).min() >= BF16_COS
-    model.release_session()

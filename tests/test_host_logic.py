@@ -104,3 +104,23 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", text, flags=re.M), os.path.join(dirpath, f)
+
+
+@pytest.mark.parametrize("arch", ["toy_base_lcm", "base_lcm_1_6B"])
+def test_base_parameter_names_and_shapes_equal_the_oracle(arch):
+    from lcm.models.base_lcm import lcm_archs
+    from lcm.models.base_lcm.builder import parameter_spec
+    from oracle.weights import base_state_dict_spec
+    mine = {n: tuple(s) for n, s, _ in parameter_spec(lcm_archs.get_config(arch))}
+    ref = {n: tuple(s) for n, s, _ in base_state_dict_spec(oracle.get_base_arch(arch))}
+    assert mine == ref
+
+
+def test_base_lcm_registry_and_no_cpu_fallback():
+    from lcm.models.base_lcm import create_base_lcm_model, lcm_archs
+    from lcm.utils.model_type_registry import lcm_model_type_registry
+    assert lcm_model_type_registry.get_model_loader("base_lcm") is not None
+    t = lcm_archs.get_config("toy_base_lcm")
+    assert (t.model_dim, t.lcm.num_layers, t.sonar_normalizer_name, t.frontend.pre_linear_bias) == (1024, 2, None, True)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        create_base_lcm_model(t, device="cpu")

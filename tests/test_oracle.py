@@ -218,3 +218,50 @@ def test_dummy_normalizer_fixture():
     x = torch.randn(4, 1024)
     cfg, m = _model("toy_two_tower_diffusion_lcm")
     assert torch.allclose(m.denormalize(m.normalize(x)), x, atol=1e-5)
+
+
+# ---- base LCM oracle ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("arch", ["toy_base_lcm", "mini_base_lcm"])
+def test_base_lcm_cache_equals_full_forward(arch):
+    """tests/units/inference/test_base_lcm_kv_caching.py of the reference, on the oracle: prefix-by-prefix decoding
+    through the KV cache equals one full causal forward."""
+    from oracle.model import KVCache
+    cfg = oracle.get_base_arch(arch)
+    sd = oracle.init_state_dict(cfg, seed=3, qk_gain=2.0, pos_std=0.5)
+    m = oracle.OracleBaseLCM(cfg, sd)
+    x = synthetic_prompts(oracle.load_dummy_normalizer(), 2, 6, seed=5) * (1.0 if m.has_normalizer else 50.0)
+    full = m.predict(x)
+    cache = KVCache(6)
+    parts = []
+    for a, b in [(0, 3), (3, 4), (4, 6)]:
+        parts.append(m.predict(x[:, a:b], cache))
+        cache.increment_step_nr(b - a)
+    got = torch.cat(parts, 1)
+    assert (got - full).abs().max() <= 1e-5 * full.abs().max()
+
+
+def test_base_lcm_generator_batched_equals_single_and_sampling():
+    """tests/units/inference/test_base_lcm_batched_inference.py of the reference, on the oracle; plus: temperature
+    noise is added in normalized space (base_lcm/builder.py:158-165)."""
+    cfg = oracle.get_base_arch("mini_base_lcm")
+    sd = oracle.init_state_dict(cfg, seed=4, qk_gain=2.0)
+    m = oracle.OracleBaseLCM(cfg, sd)
+    x = synthetic_prompts(oracle.load_dummy_normalizer(), 3, 3, seed=6)
+    nz = synthetic_noise(3, 3, seed=7)
+    gen = oracle.OracleGenerator(m, oracle.GenOptions(eos_threshold=None, lcm_temperature=0.5))
+    full = gen(x, max_gen_len=3, noise=nz)
+    for i in range(3):
+        one = gen(x[i:i + 1], max_gen_len=3, noise=nz[:, i:i + 1])
+        assert torch.allclose(one[0][0].seq, full[i][0].seq, atol=1e-6 * float(full[i][0].seq.abs().max()) + 1e-9)
+    det = oracle.OracleGenerator(m, oracle.GenOptions(eos_threshold=None, sample_latent_variable=False))(x, max_gen_len=1, noise=nz)
+    smp = oracle.OracleGenerator(m, oracle.GenOptions(eos_threshold=None, lcm_temperature=0.5))(x, max_gen_len=1, noise=nz)
+    s = sd["frontend.sonar_normalizer.scale"]
+    delta = (smp[0][0].seq[-1] - det[0][0].seq[-1]) / s
+    assert torch.allclose(delta, 0.5 * nz[0, 0], atol=1e-4)
+
+
+def test_base_lcm_parameter_count():
+    from oracle.weights import base_state_dict_spec
+    import math
+    n = sum(math.prod(s) for name, s, kind in base_state_dict_spec(oracle.get_base_arch("base_lcm_1_6B")) if kind != "normalizer")
+    assert n == 1_649_185_792      # the reconstructed 1.6B decoder; the reference's recipe comment states 1,647,635,456
