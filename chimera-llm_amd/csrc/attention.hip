@@ -12,6 +12,8 @@
 // are merged with shuffles at the end.  Two keys per lane are in flight per iteration (16 independent
 // 16-byte loads).  The query may come straight from a split-K slab (sum of partial products + bias),
 // which saves the finishing pass of the q projection.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace lcmhip {
@@ -220,6 +222,149 @@ __global__ __launch_bounds__(256) void k_attention(AttnQ qa, const T* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Causal prefill with many queries per document (bf16): a matrix-core kernel.  One workgroup = 64
+// consecutive queries of one (document, head); wave w owns queries 16w .. 16w + 15.  Keys / values are
+// walked in tiles of 32: the K tile sits row-major in LDS, the V tile TRANSPOSED ([dim][key slot], written
+// with 2-byte stores while staging), so that both products run on v_mfma_f32_16x16x32_bf16 without any
+// cross-lane exchange in between:
+//   S^T[key][query]   = K (A operand, 16 keys x 32 dims)      x Q^T (B operand, from registers)
+//   O^T[dim][query]  += V^T (A operand, 16 dims x 32 key slots) x P^T (B operand = the lane's own scores)
+// After the first product lane (query q = lane % 16, quad = lane / 16) holds the scores of keys
+// 4 quad .. 4 quad + 3 of both 16-key halves -- exactly the 8 "k slots" the second product wants from this
+// lane if key slot 8 g + e is defined as key 4 g + e (e < 4) or 16 + 4 g + e - 4 (e >= 4); the V tile is
+// stored in that slot order.  Softmax statistics are per query = per lane (replicated over the 4 quads).
+// ------------------------------------------------------------------------------------------------
+using bf16x8_t = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4_t = __attribute__((ext_vector_type(4))) uint32_t;
+using f32x4_t = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kPfKeys = 32;
+constexpr int kPfKRow = 256 + 16;                  // padded K row (bytes)
+constexpr int kPfVRow = 64 + 16;                   // padded V^T row: 32 key slots (bytes)
+
+__global__ __launch_bounds__(256) void k_attention_prefill(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
+                                                           const bf16_t* __restrict__ vc, const int32_t* __restrict__ slot_map,
+                                                           bf16_t* __restrict__ out, int s, int n_heads, int cap, int base_keys) {
+    __shared__ __attribute__((aligned(16))) char smem[kPfKeys * kPfKRow + kHeadDim * kPfVRow];
+    char* ks = smem;
+    char* vs = smem + kPfKeys * kPfKRow;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int qtiles = (s + 63) / 64;
+    const int qt = blockIdx.x % qtiles;
+    const int head = (blockIdx.x / qtiles) % n_heads;
+    const int doc = blockIdx.x / (qtiles * n_heads);
+    const int slot = slot_map ? slot_map[doc] : doc;
+    const int d = n_heads * kHeadDim;
+    const int qi = lane & 15, quad = lane >> 4;
+    const int j = qt * 64 + wid * 16 + qi;             // query index inside the document's block of s
+    const int jc = j < s ? j : s - 1;                   // rows past the end repeat the last query; never stored
+    const int my_keys = base_keys + jc + 1;             // keys this query sees
+    const int block_keys = base_keys + min(s, qt * 64 + 64);   // keys the last query of the workgroup sees
+    const int wave_keys = base_keys + min(s, qt * 64 + wid * 16 + 16);
+
+    // Q^T fragments: dims 32 * st + 8 * quad .. + 7 of query qi, pre-scaled by 1 / sqrt(128) in fp32 like the reference
+    bf16x8_t qf[4];
+    {
+        const bf16_t* qrow = q + ((size_t)doc * s + jc) * d + head * kHeadDim;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) qf[st] = *reinterpret_cast<const bf16x8_t*>(qrow + 32 * st + 8 * quad);
+    }
+    const float scale = 0.08838834764831845f;
+
+    f32x4_t o[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) o[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, l = 0.f;
+
+    const size_t hbase = ((size_t)slot * n_heads + head) * cap * kHeadDim;
+    // staging: thread -> (key = tid / 16 (+16), 16-byte piece = tid % 16) of the 32 x 256-byte tiles
+    const int skey = tid >> 4, spiece = tid & 15;
+
+    for (int k0 = 0; k0 < block_keys; k0 += kPfKeys) {
+        u32x4_t kreg[2], vreg[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int key = k0 + skey + 16 * h;
+            key = key < block_keys ? key : block_keys - 1;
+            kreg[h] = *reinterpret_cast<const u32x4_t*>(kc + hbase + (size_t)key * kHeadDim + spiece * 8);
+            vreg[h] = *reinterpret_cast<const u32x4_t*>(vc + hbase + (size_t)key * kHeadDim + spiece * 8);
+        }
+        __syncthreads();   // the previous tile is consumed
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int kk = skey + 16 * h;                                       // key inside the tile
+            *reinterpret_cast<u32x4_t*>(ks + kk * kPfKRow + spiece * 16) = kreg[h];
+            const int vslot = (kk < 16) ? (kk >> 2) * 8 + (kk & 3) : ((kk - 16) >> 2) * 8 + 4 + ((kk - 16) & 3);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t w = vreg[h][e];
+                *reinterpret_cast<uint16_t*>(vs + (spiece * 8 + 2 * e) * kPfVRow + vslot * 2) = (uint16_t)(w & 0xffffu);
+                *reinterpret_cast<uint16_t*>(vs + (spiece * 8 + 2 * e + 1) * kPfVRow + vslot * 2) = (uint16_t)(w >> 16);
+            }
+        }
+        __syncthreads();
+        if (k0 >= wave_keys) continue;   // wave-uniform: every key of the tile is masked for this wave's queries
+
+        // ---- scores of the tile's two 16-key halves
+        f32x4_t sc[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            sc[h] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(ks + (16 * h + qi) * kPfKRow + 64 * st + 16 * quad);
+                sc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[st], sc[h], 0, 0, 0);
+            }
+        }
+        float p[8];
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = k0 + 16 * h + 4 * quad + e;
+                const float v = key < my_keys ? sc[h][e] * scale : -INFINITY;
+                p[4 * h + e] = v;
+                tmax = fmaxf(tmax, v);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mn = fmaxf(m, tmax);                 // finite: key 0 is visible to every query
+        const float alpha = __expf(m - mn);
+        float psum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            p[e] = __expf(p[e] - mn);
+            psum += p[e];
+        }
+        psum += __shfl_xor(psum, 16, 64);
+        psum += __shfl_xor(psum, 32, 64);
+        l = l * alpha + psum;
+        m = mn;
+        bf16x8_t pf;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pf[e] = (__bf16)p[e];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            o[t] *= alpha;
+            const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vs + (16 * t + qi) * kPfVRow + 16 * quad);
+            o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[t], 0, 0, 0);
+        }
+    }
+    if (j < s) {
+        const float inv = 1.f / l;
+        bf16_t* orow = out + ((size_t)doc * s + j) * d + head * kHeadDim;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            uint2 pk;
+            pk.x = (uint32_t)f32_to_bf16(o[t][0] * inv) | ((uint32_t)f32_to_bf16(o[t][1] * inv) << 16);
+            pk.y = (uint32_t)f32_to_bf16(o[t][2] * inv) | ((uint32_t)f32_to_bf16(o[t][3] * inv) << 16);
+            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(orow) + 16 * t + 4 * quad) = pk;
+        }
+    }
+}
+
 int launch_attention_q(const AttnQ& qa, const void* kc, const void* vc, const int32_t* slot_map, void* out, int n_docs,
                        int s, int n_heads, int cap, int base_keys, int causal, int dtype, hipStream_t st) {
     LCM_REQUIRE(n_heads % 4 == 0 || n_heads == 2, "attention: heads must be a multiple of 4 (or 2)");
@@ -228,6 +373,15 @@ int launch_attention_q(const AttnQ& qa, const void* kc, const void* vc, const in
     LCM_REQUIRE(max_keys >= 1 && max_keys <= cap, "attention: key range exceeds the cache");
     LCM_REQUIRE((qa.q != nullptr) != (qa.partial != nullptr), "attention: exactly one query source");
     if (n_docs == 0) return LCMHIP_OK;
+    static const int prefill_min = [] { const char* e = getenv("LCMHIP_PREFILL_MIN"); return e ? atoi(e) : 16; }();
+    if (causal && dtype == LCMHIP_BF16 && qa.q != nullptr && s >= prefill_min) {
+        const int qtiles = (s + 63) / 64;
+        hipLaunchKernelGGL(k_attention_prefill, dim3((unsigned)(n_docs * n_heads * qtiles)), dim3(256), 0, st,
+                           (const bf16_t*)qa.q, (const bf16_t*)kc, (const bf16_t*)vc, slot_map, (bf16_t*)out, s, n_heads, cap,
+                           base_keys);
+        LCM_HIP_CHECK(hipGetLastError());
+        return LCMHIP_OK;
+    }
     const int waves = n_heads >= 4 ? 4 : n_heads;
     dim3 grid((unsigned)(n_docs * s * (n_heads / waves))), block(64 * waves);
     if (dtype == LCMHIP_BF16)

@@ -266,7 +266,8 @@ static size_t carve(lcmhip_session* s, char* base) {
     s->act_o = c.take<char>(R * dm * es);
     s->act_h = c.take<char>(R * F * es);
     s->kept_ctx = s->keep_context ? c.take<float>(B * cap * dm * 4) : nullptr;
-    s->slab_bytes = (size_t)kMaxSplits * R * std::max(dm, D) * 4;
+    // split-K slabs: every split of a denoiser-sized problem (2 rows per document), or two slabs of a full chunk
+    s->slab_bytes = std::max((size_t)kMaxSplits * std::max<size_t>(2 * B, 512), 2 * R) * std::max(dm, D) * 4;
     s->slab_p = c.take<float>(s->slab_bytes);
     s->slab_q = c.take<float>(s->slab_bytes);
     return c.off;
@@ -571,7 +572,8 @@ static int session_dims(lcmhip_session* s, const lcmhip_model* m, int max_batch,
     s->max_batch = max_batch;
     s->cap = max_ctx;
     s->max_steps = max_steps;
-    s->chunk_rows = std::max(2 * max_batch, 512);
+    // rows of one contextualizer pass: large enough for matrix-core-bound GEMMs when a prompt is long
+    s->chunk_rows = std::max(2 * max_batch, (int)std::min<int64_t>(4096, std::max<int64_t>(512, (int64_t)max_batch * max_ctx)));
     s->rows_cap = std::max(s->chunk_rows, max_steps);
     s->keep_context = env_flag("LCMHIP_KEEP_CONTEXT");
     return LCMHIP_OK;

@@ -210,11 +210,12 @@ def test_ddim_cfg_step(hip, mode):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("causal,s,base", [(0, 1, 1), (0, 1, 137), (1, 1, 40), (1, 7, 0), (1, 5, 66)])
+@pytest.mark.parametrize("causal,s,base", [(0, 1, 1), (0, 1, 137), (1, 1, 40), (1, 7, 0), (1, 5, 66),
+                                           (1, 16, 5), (1, 64, 0), (1, 130, 37), (1, 200, 0)])
 def test_attention(hip, dtype, causal, s, base):
     from oracle.model import sdpa
     torch.manual_seed(5)
-    n_docs, H, cap = 3, 8, 160
+    n_docs, H, cap = 3, 8, 256
     d = H * 128
     kc = torch.randn(4, H, cap, 128).cuda().to(dtype)  # [slot][head][position][128]; documents -> slots 2, 0, 3
     vc = torch.randn(4, H, cap, 128).cuda().to(dtype)
