@@ -1,0 +1,44 @@
+"""BASELINE config 5 (bounded sample): two-tower 1.6B, long context, 100 denoising steps, large batch.
+Documents start with a long prompt (one matrix-core prefill) and generate a few sentences at context ~500:
+the KV-streaming regime.  Prints one JSON line with throughput, time per diffusion step and the kernel table."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from lcm.datasets.batch import EmbeddingsBatch
+from lcm.inference.two_tower_diffusion_lcm import DiffusionLCMGeneratorOptions, TwoTowerDiffusionLCMGenerator
+from lcm.models.two_tower_diffusion_lcm import create_two_tower_diffusion_lcm_model, lcm_archs
+
+B = int(os.environ.get("LC_BATCH", "512")); P = int(os.environ.get("LC_PROMPT", "496")); G = int(os.environ.get("LC_GEN", "4"))
+dev = torch.device("cuda:0")
+model = create_two_tower_diffusion_lcm_model(lcm_archs.get_config(bench.ARCH), device=dev, dtype=torch.bfloat16, seed=0)
+model.init_parameters(seed=0, modulator_std=0.2)
+opts = dict(bench.OPTS, inference_timesteps=100, max_seq_len=max(G, 128))
+gen = TwoTowerDiffusionLCMGenerator(model, DiffusionLCMGeneratorOptions(**opts))
+c, s = model.sonar_normalizer.center.float(), model.sonar_normalizer.scale.float()
+g = torch.Generator(device=dev).manual_seed(1234)
+prompts = (c + s * torch.randn(B, P, 1024, generator=g, device=dev)).to(model.dtype)
+noise = torch.randn(G, B, 1024, generator=g, device=dev)
+
+def run(glen):
+    out = gen(EmbeddingsBatch(prompts, None), max_gen_len=glen, noise=noise[:glen])
+    torch.cuda.synchronize()
+    return out
+
+run(1)                                    # warm-up: session, schedule tables
+t0 = time.perf_counter(); run(1); t1 = time.perf_counter() - t0      # prefill + 1 sentence
+t0 = time.perf_counter(); out = run(G); tG = time.perf_counter() - t0
+per_sentence = (tG - t1) / (G - 1) if G > 1 else t1
+assert all(torch.isfinite(h[0].seq.float()).all() for h in out.hypotheses)
+sess = model._session_pool[0]
+sess.profile_enable(True); run(1)
+rows = sess.profile(); sess.profile_enable(False)
+table = {r["name"]: dict(launches=r["launches"], ms=round(r["total_ms"], 2),
+                         gbps=round(r["bytes"] / r["total_ms"] / 1e6, 1) if r["total_ms"] > 0 else None,
+                         tflops=round(r["flops"] / r["total_ms"] / 1e9, 1) if r["total_ms"] > 0 else None)
+         for r in rows if r["launches"]}
+steps = len(model.noise_scheduler.timesteps)
+print(json.dumps({"workload": f"two_tower_diffusion_lcm_1_6B long context: {B} docs, prompt {P}, {G} generated, {steps} DDIM steps, CFG, bf16",
+                  "sentence_embeddings_per_s_at_context": round(B / per_sentence, 1), "ms_per_sentence_step": round(per_sentence * 1e3, 1),
+                  "ms_per_diffusion_step": round(per_sentence * 1e3 / steps, 3), "prefill_plus_first_sentence_s": round(t1, 2),
+                  "kernels": table}))
