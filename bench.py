@@ -149,11 +149,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     distributed = world > 1
+    # rehearsal on a one-GPU box: LCM_BENCH_BACKEND=gloo LCM_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
+    # gathers through the host; the real multi-GPU run uses RCCL ("nccl") with one rank per GPU
+    backend = os.environ.get("LCM_BENCH_BACKEND", "nccl")
+    if os.environ.get("LCM_BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from lcm.datasets.batch import EmbeddingsBatch
     from lcm.inference.two_tower_diffusion_lcm import DiffusionLCMGeneratorOptions, TwoTowerDiffusionLCMGenerator
@@ -180,7 +188,11 @@ def main():
             seqs = torch.stack([h[0].seq for h in out.hypotheses])           # (B, P+G, D)
             lens = torch.tensor([h[0].seq.shape[0] for h in out.hypotheses], device=device, dtype=torch.int32)
             if distributed:
-                seqs, lens = all_gather_generations(seqs, lens)
+                if backend == "nccl":
+                    seqs, lens = all_gather_generations(seqs, lens)
+                else:
+                    seqs, lens = all_gather_generations(seqs.cpu(), lens.cpu())
+                    seqs, lens = seqs.to(device), lens.to(device)
         return seqs, lens
 
     def fence():
@@ -197,7 +209,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     generated = int((lens.to(torch.int64) - P).sum().item())                 # all ranks' documents after the gather
