@@ -1,0 +1,68 @@
+"""Model-card + checkpoint loading on the HIP path, the way the reference's cards are written
+(lcm/utils/card_utils.py:178-223, README.md:187-199): `checkpoint: file://.../model.pt` holding
+`{"model": state_dict}`, DDP `module.` prefixes (lcm/models/base_lcm/loader.py:24-30), half-precision
+checkpoints cast to the requested dtype, `model_config` overrides, and the normalizer taken from its own card when
+the checkpoint does not carry it."""
+
+import pytest
+import torch
+import yaml
+
+import oracle
+from parity_utils import DEFAULT_OPTS, compare, make_problem, run_hip, run_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_tower_card_roundtrip(tmp_path):
+    from lcm.utils.card_utils import load_model_from_card
+    arch = "toy_two_tower_diffusion_lcm"
+    cfg, sd, x, nz = make_problem(arch, 2, 3, 2, seed=5)
+    # a checkpoint as a DDP fp16 training run leaves it, without the normalizer buffers
+    ckpt = {"model": {"module." + k: v.half() for k, v in sd.items() if not k.startswith("sonar_normalizer.")}}
+    torch.save(ckpt, tmp_path / "model.pt")
+    card = {"name": "tmp_two_tower", "model_family": "two_tower_diffusion_lcm", "model_arch": arch,
+            "checkpoint": "file://" + str(tmp_path / "model.pt"),
+            "model_config": {"trained_with_cf_guidance": True, "noise_scheduler": {"num_diffusion_train_steps": 1000}}}
+    with open(tmp_path / "model_card.yaml", "w") as f:
+        yaml.safe_dump(card, f)
+    model = load_model_from_card(str(tmp_path / "model_card.yaml"), device="cuda:0", dtype=torch.float32)
+    assert model.config.trained_with_cf_guidance and model.dtype == torch.float32
+    # the dummy normalizer card supplied center / scale
+    assert torch.allclose(model.sonar_normalizer.center.cpu(), sd["sonar_normalizer.center"])
+    sd16 = {k: (v if k.startswith("sonar_normalizer.") else v.half().float()) for k, v in sd.items()}
+    opts = dict(DEFAULT_OPTS, inference_timesteps=5)
+    ref = run_oracle(cfg, sd16, x, nz, 2, opts)
+    out, _ = run_hip(arch, None, x, nz, 2, opts, model=model)
+    worst, cos = compare(out.hypotheses, ref, sd, start=3)
+    assert worst <= 1e-3 and cos >= 0.9999, (worst, cos)
+
+
+def test_base_card_roundtrip_and_directory_card(tmp_path):
+    from lcm.datasets.batch import EmbeddingsBatch
+    from lcm.utils.card_utils import load_model_from_card
+    cfg = oracle.get_base_arch("toy_base_lcm")
+    sd = oracle.init_state_dict(cfg, seed=9, qk_gain=2.0, pos_std=0.5)
+    torch.save({"model": sd}, tmp_path / "model.pt")
+    with open(tmp_path / "model_card.yaml", "w") as f:
+        yaml.safe_dump({"name": "tmp_base", "model_family": "base_lcm", "model_arch": "toy_base_lcm",
+                        "checkpoint": "model.pt"}, f)          # path relative to the card, card given as a directory
+    model = load_model_from_card(str(tmp_path), device="cuda:0", dtype=torch.float32)
+    x = torch.randn(2, 5, 1024)
+    ref = oracle.OracleBaseLCM(cfg, sd).predict(x)
+    out = model.predict_next_sentence(EmbeddingsBatch(x.cuda(), None)).seqs.cpu()
+    assert (out - ref).abs().max() <= 2e-4 * ref.abs().max()
+
+
+def test_strict_loading_errors():
+    from lcm.models.two_tower_diffusion_lcm import create_two_tower_diffusion_lcm_model, lcm_archs
+    model = create_two_tower_diffusion_lcm_model(lcm_archs.get_config("toy_two_tower_diffusion_lcm"), device="cuda:0")
+    sd = dict(model.state_dict())
+    bad = dict(sd)
+    bad.pop("denoiser.final_proj.fc.bias")
+    with pytest.raises(RuntimeError, match="missing keys"):
+        model.load_state_dict(bad)
+    bad = dict(sd)
+    bad["denoiser.final_proj.fc.bias"] = torch.zeros(7)
+    with pytest.raises(RuntimeError, match="shape mismatch"):
+        model.load_state_dict(bad)
