@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Headline benchmark: sentence-embeddings generated/s, 1.6B two-tower LCM, 40 diffusion steps.
 
-One "step" is one full `TwoTowerDiffusionLCMGenerator(batch)` call on the workload of BASELINE
-config 3: 64 documents per GPU, 8 prompt sentences, 128 generated sentences, 40 requested DDIM
+One "step" is one full `TwoTowerDiffusionLCMGenerator(batch)` call on the headline workload:
+64 documents per GPU, 8 prompt sentences, 128 generated sentences, 40 requested DDIM
 steps (50 executed, because the reference's integer `arange` truncates the step of the trailing
 schedule), classifier-free guidance w=3 / rescale 0.7, bf16 weights, synthetic prompts, seeded
 random-init weights and host-supplied noise indexed by global document id.  With N > 1 ranks
@@ -227,7 +227,7 @@ def main():
             "value": round(generated / (elapsed / args.steps), 2), "unit": "sentence-embeddings/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"BASELINE config 3: {args.arch}, random-init, {B} docs/GPU x {P} prompt + {G} generated "
+            "config": {"workload": f"headline config: {args.arch}, random-init, {B} docs/GPU x {P} prompt + {G} generated "
                                    f"sentences, 40 requested = 50 executed DDIM steps, CFG w=3 rescale=0.7",
                        "global_batch": world * B, "prompt_len": P, "gen_len": G, "executed_ddim_steps": 50,
                        "parallelism": f"dp{world} by document, one all-gather of outputs"},

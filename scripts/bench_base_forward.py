@@ -1,4 +1,4 @@
-"""BASELINE config 2: base_lcm 1.6B next-concept regression forward, batch 32 x 128 concepts, bf16, one MI355X.
+"""Base-LCM benchmark configuration: base_lcm 1.6B next-concept regression forward, batch 32 x 128 concepts, bf16, one MI355X.
 Prints one JSON line: forwards/s, concepts/s, TFLOP/s against the dense bf16 matrix-core peak, per-kernel table."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,4 +1,4 @@
-"""BASELINE config 5 (bounded sample): two-tower 1.6B, long context, 100 denoising steps, large batch.
+"""Long-context benchmark configuration (bounded sample): two-tower 1.6B, long context, 100 denoising steps, large batch.
 Documents start with a long prompt (one matrix-core prefill) and generate a few sentences at context ~500:
 the KV-streaming regime.  Prints one JSON line with throughput, time per diffusion step and the kernel table."""
 import json, os, sys, time

@@ -1,5 +1,5 @@
 """Parity of the base (MSE) LCM on the HIP path against the CPU oracle: forward over whole sequences
-(BASELINE config 2's shape, reduced) and sentence-by-sentence generation with the KV cache.
+(the base-LCM benchmark shape, reduced) and sentence-by-sentence generation with the KV cache.
 
 Tolerances as for the two-tower path: fp32 max-abs <= 1e-3 (normalizer units) and cosine >= 0.9999; bf16
 cosine >= 0.999.  The reference's own invariants for this generator are restated on the HIP path:

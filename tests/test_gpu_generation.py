@@ -1,7 +1,7 @@
 """End-to-end parity of the HIP generation path against the CPU oracle on identical seeded
 weights, prompts and host-supplied noise.
 
-Tolerances (BASELINE north star): fp32 -- max-abs <= 1e-3 (in normalizer units, i.e. the space
+Tolerances: fp32 -- max-abs <= 1e-3 (in normalizer units, i.e. the space
 the model works in) and per-embedding cosine >= 0.9999; bf16 -- cosine >= 0.999.
 """
 
@@ -17,7 +17,7 @@ FP32_MAX_ABS, FP32_COS, BF16_COS = 1e-3, 0.9999, 0.999
 
 
 def test_toy_fp32_config1():
-    """BASELINE config 1: toy arch, 8 docs x (4 prompt + 12 generated), 10 DDIM steps, CFG."""
+    """The CPU-runnable benchmark configuration: toy arch, 8 docs x (4 prompt + 12 generated), 10 DDIM steps, CFG."""
     arch = "toy_two_tower_diffusion_lcm"
     cfg, sd, x, nz = make_problem(arch, 8, 4, 12)
     opts = dict(DEFAULT_OPTS, inference_timesteps=10)
@@ -138,7 +138,7 @@ def test_toy_fp32_against_golden_fixture():
 
 @pytest.mark.timeout(900)
 def test_1_6b_bf16_reduced_batch():
-    """BASELINE config 3's architecture (1.6B, bf16, 40 requested -> 50 executed steps, CFG 3.0 / 0.7) at
+    """The headline configuration's architecture (1.6B, bf16, 40 requested -> 50 executed steps, CFG 3.0 / 0.7) at
     a batch the fp32 CPU oracle finishes in about a minute: 4 docs x (3 prompt + 2 generated).
 
     The random weights use milder gains than the small-model tests (modulator x4, q/k x1): with the x10 / x2
