@@ -7,8 +7,10 @@
 // tile row is 128 contiguous bytes.  Staging is global -> LDS by LDS-DMA (global_load_lds, 16 bytes per lane):
 // one wave instruction fills 8 rows x 128 B of the stage, lane l -> (row l / 8, 16-byte slot l % 8).  The LDS
 // image stays lane-linear; bank conflicts of the fragment reads (16 rows x one 16-byte slot) are removed by
-// swizzling on the SOURCE side: slot s of row r holds the K piece s ^ (r % 8).  Two stages: the DMA of K tile
-// t + 1 runs while the matrix cores consume tile t; one barrier per K tile.
+// swizzling on the SOURCE side: slot s of row r holds the K piece s ^ ((r / 2) % 8).  Two stages: the DMA of K tile
+// t + 1 runs while the matrix cores consume tile t; one barrier per K tile.  (A three-stage variant with one
+// workgroup per CU and a counted vmcnt across a bare s_barrier measured 20-25 % slower than two stages with two
+// workgroups per CU.)
 #include "common.h"
 #include "gemm_epilogue.h"
 
@@ -40,7 +42,10 @@ __global__ __launch_bounds__(256) void k_gemm_big(GemmArgs p) {
     // 16..31 = weight rows.  This lane's row inside a group is lane / 8, its slot lane % 8 receives K piece
     // (lane % 8) ^ (lane / 8).
     const int srow = lane >> 3;
-    const size_t piece_off = (size_t)(((lane & 7) ^ srow) * 16);
+    // swizzle: slot s of tile row r holds K piece s ^ ((r / 2) % 8).  Two consecutive rows share one 256-byte bank
+    // line, so the 16 rows x one piece of a fragment read land on 16 distinct 16-byte bank groups.  For the rows
+    // this lane stages, r = 8 * (wid + 4 j) + srow, hence (r / 2) % 8 = 4 * (wid % 2) + srow / 2 for every j.
+    const size_t piece_off = (size_t)(((lane & 7) ^ (4 * (wid & 1) + (srow >> 1))) * 16);
     const char* src[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -77,7 +82,7 @@ __global__ __launch_bounds__(256) void k_gemm_big(GemmArgs p) {
 
     // fragment addresses: row = tile row base + lane % 16, K piece of k-step ks = 4 * ks + lane / 16
     const int frow = lane & 15;
-    const int fsw = frow & 7;
+    const int fsw = (frow >> 1) & 7;   // tile row bases are multiples of 16
     const int x_row0 = wm * 64 + frow;
     const int w_row0 = kBM + wn * 64 + frow;
 
