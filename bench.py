@@ -232,7 +232,7 @@ def main():
                        "global_batch": world * B, "prompt_len": P, "gen_len": G, "executed_ddim_steps": 50,
                        "parallelism": f"dp{world} by document, one all-gather of outputs"},
         }
-    if rank == 0 and world == 1 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline:      # the other ranks wait at the final barrier meanwhile
         with torch.cuda.stream(stream):
             roof, table = roofline_pass(model, TwoTowerDiffusionLCMGenerator, DiffusionLCMGeneratorOptions, B, P, G, device)
         result["roofline"] = roof

@@ -23,6 +23,12 @@ __global__ __launch_bounds__(256) void k_normalizer(const TI* __restrict__ x, co
     float c[8], s[8], lo[8], hi[8];
     load8<TP>(center + col, c);
     load8<TP>(scale + col, s);
+    if (!INVERSE) {
+        // one exact division per column group, then a multiply per element (differs from a per-element division by
+        // at most one fp32 ulp; the division sequence would otherwise make the kernel VALU- rather than HBM-bound)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = 1.f / s[j];
+    }
     const bool clip = cmin != nullptr;
     if (clip) {
         load8<TP>(cmin + col, lo);
@@ -45,7 +51,7 @@ __global__ __launch_bounds__(256) void k_normalizer(const TI* __restrict__ x, co
                 for (int j = 0; j < 8; ++j) v[u][j] = v[u][j] * s[j] + c[j];
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[u][j] = (v[u][j] - c[j]) / s[j];
+                for (int j = 0; j < 8; ++j) v[u][j] = (v[u][j] - c[j]) * s[j];
                 if (clip) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[u][j] = fminf(fmaxf(v[u][j], lo[j]), hi[j]);
