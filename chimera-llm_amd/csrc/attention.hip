@@ -59,7 +59,8 @@ __device__ __forceinline__ void unpack8<float>(const Piece<float>& r, float (&v)
 template <typename T>
 __global__ __launch_bounds__(256) void k_attention(AttnQ qa, const T* __restrict__ kc, const T* __restrict__ vc,
                                                    const int32_t* __restrict__ slot_map, T* __restrict__ out, int s,
-                                                   int n_heads, int cap, int base_keys, int causal) {
+                                                   int n_heads, int cap, int base_keys, int causal,
+                                                   const int32_t* __restrict__ base_keys_dev) {
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int heads_per_block = blockDim.x >> 6;
     const int hb = n_heads / heads_per_block;           // blocks per query row
@@ -67,7 +68,8 @@ __global__ __launch_bounds__(256) void k_attention(AttnQ qa, const T* __restrict
     const int head = (blockIdx.x % hb) * heads_per_block + wid;
     const int doc = row / s, j = row % s;
     const int slot = slot_map ? slot_map[doc] : doc;
-    const int nkeys = base_keys + (causal ? j + 1 : 0);
+    // a launch recorded in a graph reads the key count from device memory: it changes with every appended position
+    const int nkeys = (base_keys_dev ? *base_keys_dev : base_keys) + (causal ? j + 1 : 0);
     const int d = n_heads * kHeadDim;
     const int ks = lane >> 2, dg = lane & 3;
     const int col = head * kHeadDim + dg * 8;           // piece i of this lane starts at col + 32 * i
@@ -366,7 +368,8 @@ __global__ __launch_bounds__(256) void k_attention_prefill(const bf16_t* __restr
 }
 
 int launch_attention_q(const AttnQ& qa, const void* kc, const void* vc, const int32_t* slot_map, void* out, int n_docs,
-                       int s, int n_heads, int cap, int base_keys, int causal, int dtype, hipStream_t st) {
+                       int s, int n_heads, int cap, int base_keys, int causal, int dtype, hipStream_t st,
+                       const int32_t* base_keys_dev) {
     LCM_REQUIRE(n_heads % 4 == 0 || n_heads == 2, "attention: heads must be a multiple of 4 (or 2)");
     LCM_REQUIRE(n_docs >= 0 && s >= 1 && base_keys >= 0, "attention: bad shape");
     const int max_keys = base_keys + (causal ? s : 0);
@@ -374,7 +377,7 @@ int launch_attention_q(const AttnQ& qa, const void* kc, const void* vc, const in
     LCM_REQUIRE((qa.q != nullptr) != (qa.partial != nullptr), "attention: exactly one query source");
     if (n_docs == 0) return LCMHIP_OK;
     static const int prefill_min = [] { const char* e = getenv("LCMHIP_PREFILL_MIN"); return e ? atoi(e) : 4; }();   // shortest causal query block that takes the matrix-core kernel
-    if (causal && dtype == LCMHIP_BF16 && qa.q != nullptr && s >= prefill_min) {
+    if (causal && dtype == LCMHIP_BF16 && qa.q != nullptr && s >= prefill_min && base_keys_dev == nullptr) {
         const int qtiles = (s + 63) / 64;
         hipLaunchKernelGGL(k_attention_prefill, dim3((unsigned)(n_docs * n_heads * qtiles)), dim3(256), 0, st,
                            (const bf16_t*)qa.q, (const bf16_t*)kc, (const bf16_t*)vc, slot_map, (bf16_t*)out, s, n_heads, cap,
@@ -386,10 +389,10 @@ int launch_attention_q(const AttnQ& qa, const void* kc, const void* vc, const in
     dim3 grid((unsigned)(n_docs * s * (n_heads / waves))), block(64 * waves);
     if (dtype == LCMHIP_BF16)
         hipLaunchKernelGGL((k_attention<bf16_t>), grid, block, 0, st, qa, (const bf16_t*)kc, (const bf16_t*)vc, slot_map,
-                           (bf16_t*)out, s, n_heads, cap, base_keys, causal);
+                           (bf16_t*)out, s, n_heads, cap, base_keys, causal, base_keys_dev);
     else if (dtype == LCMHIP_F32)
         hipLaunchKernelGGL((k_attention<float>), grid, block, 0, st, qa, (const float*)kc, (const float*)vc, slot_map,
-                           (float*)out, s, n_heads, cap, base_keys, causal);
+                           (float*)out, s, n_heads, cap, base_keys, causal, base_keys_dev);
     else
         return fail(LCMHIP_ERR_INVALID, "attention: unknown dtype");
     LCM_HIP_CHECK(hipGetLastError());
@@ -400,7 +403,7 @@ int launch_attention(const void* q, const void* kc, const void* vc, const int32_
                      int s, int n_heads, int cap, int base_keys, int causal, int dtype, hipStream_t st) {
     AttnQ qa{};
     qa.q = q;
-    return launch_attention_q(qa, kc, vc, slot_map, out, n_docs, s, n_heads, cap, base_keys, causal, dtype, st);
+    return launch_attention_q(qa, kc, vc, slot_map, out, n_docs, s, n_heads, cap, base_keys, causal, dtype, st, nullptr);
 }
 
 }  // namespace lcmhip

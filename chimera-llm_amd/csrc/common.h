@@ -194,7 +194,8 @@ struct AttnQ {
     const void* bias;
 };
 int launch_attention_q(const AttnQ& qa, const void* kc, const void* vc, const int32_t* slot_map, void* out, int n_docs,
-                       int s, int n_heads, int cap, int base_keys, int causal, int dtype, hipStream_t st);
+                       int s, int n_heads, int cap, int base_keys, int causal, int dtype, hipStream_t st,
+                       const int32_t* base_keys_dev = nullptr);
 
 struct DdimScalars {
     float sqrt_a_t, sqrt_b_t;        // sqrt(alpha_prod_t), sqrt(1 - alpha_prod_t)

@@ -196,6 +196,9 @@ struct lcmhip_session {
          *act_in = nullptr;
     float* kept_ctx = nullptr;
     float *slab_p = nullptr, *slab_q = nullptr;   // split-K slabs: pending products / internal finishing
+    int32_t* d_cross_keys = nullptr;              // device copy of ctx_len + 1 (read by graph-recorded attention launches)
+    float *noise_buf = nullptr, *out_buf = nullptr;   // fixed addresses for graph-recorded denoising
+    std::map<int, hipGraphExec_t> graphs;         // one recorded denoising loop per number of active documents
     size_t slab_bytes = 0;
     // host state
     std::vector<int32_t> h_slot;
@@ -270,6 +273,9 @@ static size_t carve(lcmhip_session* s, char* base) {
     s->slab_bytes = std::max((size_t)kMaxSplits * std::max<size_t>(2 * B, 512), 2 * R) * std::max(dm, D) * 4;
     s->slab_p = c.take<float>(s->slab_bytes);
     s->slab_q = c.take<float>(s->slab_bytes);
+    s->d_cross_keys = c.take<int32_t>(256);
+    s->noise_buf = c.take<float>(B * D * 4);
+    s->out_buf = c.take<float>(B * D * 4);
     return c.off;
 }
 
@@ -287,6 +293,8 @@ __global__ void k_make_rows(const int32_t* __restrict__ slot_map, int32_t* pos, 
     self_rows[r] = slot * cap + p;
     cross_rows[r] = slot * (cap + 1) + p + 1;
 }
+
+__global__ void k_set_int(int32_t* p, int32_t v) { *p = v; }
 
 __global__ void k_slot0_rows(int32_t* slot0_rows, int32_t* slot_map, int n, int cap1) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -614,7 +622,13 @@ int lcmhip_session_create(lcmhip_model* m, int32_t max_batch, int32_t max_ctx, i
     return LCMHIP_OK;
 }
 
+static void drop_graphs(lcmhip_session* s) {
+    for (auto& kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
+    s->graphs.clear();
+}
+
 int lcmhip_session_destroy(lcmhip_session* s) {
+    if (s) drop_graphs(s);
     delete s;
     return LCMHIP_OK;
 }
@@ -630,6 +644,7 @@ int lcmhip_session_reset(lcmhip_session* s, int32_t n_docs, void* stream) {
     const lcmhip_model_desc& d = m->desc;
     s->n_active = n_docs;
     s->ctx_len = 0;
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, s->d_cross_keys, 1);
     s->h_slot.resize(n_docs);
     for (int i = 0; i < n_docs; ++i) s->h_slot[i] = i;
     hipLaunchKernelGGL(k_slot0_rows, dim3((n_docs + 255) / 256), dim3(256), 0, st, s->slot0_rows, s->slot_map, n_docs,
@@ -671,6 +686,7 @@ int lcmhip_session_set_schedule(lcmhip_session* s, const int32_t* timesteps, int
                                 int32_t step_ratio, const lcmhip_denoise_params* params, void* stream) {
     LCM_REQUIRE(s && timesteps && alphas_cumprod && params, "set_schedule: null argument");
     LCM_REQUIRE(!s->model->base, "set_schedule: a base LCM has no diffusion schedule");
+    drop_graphs(s);   // recorded loops hold the old schedule's scalars
     LCM_REQUIRE(n_steps >= 1 && n_steps <= s->max_steps, "set_schedule: more steps than the session was sized for");
     if (params->ddim_eta != 0.f)
         return fail(LCMHIP_ERR_UNSUPPORTED, "ddim_eta != 0 (stochastic DDIM) is not implemented");
@@ -825,6 +841,8 @@ static int append_impl(lcmhip_session* s, const float* x, int32_t n_tokens, int3
         }
     }
     s->ctx_len += n_tokens;
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), s->d_cross_keys, s->ctx_len + 1);
+    LCM_HIP_CHECK(hipGetLastError());
     return LCMHIP_OK;
 }
 
@@ -854,12 +872,10 @@ int lcmhip_session_read_context(lcmhip_session* s, int32_t row, float* out, void
 }
 
 // ------------------------------------------------------------------------------------------------ denoising loop
-int lcmhip_denoise(lcmhip_session* s, const float* noise, float* out, float* latents_trace, void* stream) {
-    LCM_REQUIRE(s && noise && out, "denoise: null argument");
-    LCM_REQUIRE(!s->model->base, "denoise: a base LCM has no denoiser (use lcmhip_base_forward)");
-    if (!s->have_schedule) return fail(LCMHIP_ERR_STATE, "denoise: call session_set_schedule first");
-    LCM_REQUIRE(s->n_active >= 1 && s->ctx_len >= 1, "denoise: empty context (append at least one position first)");
-    hipStream_t st = static_cast<hipStream_t>(stream);
+// The whole sampling loop of one sentence.  `keys_dev` != nullptr makes the attention launches read the key
+// count from device memory (the form that is recorded into a graph and replayed for later sentences).
+static int denoise_body(lcmhip_session* s, const float* noise, float* out, float* latents_trace, hipStream_t st,
+                        const int32_t* keys_dev) {
     lcmhip_model* m = s->model;
     const lcmhip_model_desc& d = m->desc;
     const lcmhip_tower_desc& td = d.denoiser;
@@ -904,7 +920,7 @@ int lcmhip_denoise(lcmhip_session* s, const float* noise, float* out, float* lat
                 ProfScope ps(&s->prof, "den.cross_attn", 2.0 * B * (double)nkeys * dm * es + B * dm * (es + 4.0 * qp.splits),
                              4.0 * B * (double)nkeys * dm, st);
                 LCM_TRY(launch_attention_q(qa, s->cross_k + l * cross_layer, s->cross_v + l * cross_layer, s->slot_map,
-                                           s->act_o, B, 1, td.num_heads, s->cap + 1, nkeys, 0, d.dtype, st));
+                                           s->act_o, B, 1, td.num_heads, s->cap + 1, nkeys, 0, d.dtype, st, keys_dev));
             }
             LCM_TRY(gemm_pending(s, "den.cross_o", s->act_o, dm, Ly.ca.o, mod + 5 * dm, B, &pend, st));
             pend.extra_const = s->uconst + (size_t)l * dm;
@@ -923,6 +939,44 @@ int lcmhip_denoise(lcmhip_session* s, const float* noise, float* out, float* lat
             LCM_HIP_CHECK(hipMemcpyAsync(latents_trace + (size_t)si * B * D, lat, (size_t)B * D * 4, hipMemcpyDeviceToDevice, st));
     }
     return launch_denormalize_f32_out(s->x0, m->center, m->scale, out, B, D, d.dtype, st);
+}
+
+int lcmhip_denoise(lcmhip_session* s, const float* noise, float* out, float* latents_trace, void* stream) {
+    LCM_REQUIRE(s && noise && out, "denoise: null argument");
+    LCM_REQUIRE(!s->model->base, "denoise: a base LCM has no denoiser (use lcmhip_base_forward)");
+    if (!s->have_schedule) return fail(LCMHIP_ERR_STATE, "denoise: call session_set_schedule first");
+    LCM_REQUIRE(s->n_active >= 1 && s->ctx_len >= 1, "denoise: empty context (append at least one position first)");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // Graph replay: the loop is ~6000 launches per sentence whose arguments depend only on the schedule and on
+    // the number of active documents, so it is recorded once per session and replayed.  Needs a non-default
+    // stream (capture is not defined on the legacy stream); per-launch profiling and latent traces run eagerly.
+    const char* genv = getenv("LCMHIP_GRAPH");   // read per call: tests switch it within one process
+    const bool graphs_on = !genv || atoi(genv) != 0;
+    if (!graphs_on || st == nullptr || s->prof.enabled || latents_trace != nullptr)
+        return denoise_body(s, noise, out, latents_trace, st, nullptr);
+    const size_t io_bytes = (size_t)s->n_active * s->model->desc.sonar_dim * 4;
+    auto it = s->graphs.find(s->n_active);
+    if (it == s->graphs.end()) {
+        if (s->graphs.size() >= 16) drop_graphs(s);   // documents finishing one by one: keep the cache bounded
+        hipGraph_t graph = nullptr;
+        LCM_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        const int rc = denoise_body(s, s->noise_buf, s->out_buf, nullptr, st, s->d_cross_keys);
+        const hipError_t end = hipStreamEndCapture(st, &graph);
+        if (rc != LCMHIP_OK) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc;
+        }
+        LCM_HIP_CHECK(end);
+        hipGraphExec_t exec = nullptr;
+        const hipError_t inst = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        LCM_HIP_CHECK(inst);
+        it = s->graphs.emplace(s->n_active, exec).first;
+    }
+    LCM_HIP_CHECK(hipMemcpyAsync(s->noise_buf, noise, io_bytes, hipMemcpyDeviceToDevice, st));
+    LCM_HIP_CHECK(hipGraphLaunch(it->second, st));
+    LCM_HIP_CHECK(hipMemcpyAsync(out, s->out_buf, io_bytes, hipMemcpyDeviceToDevice, st));
+    return LCMHIP_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ profiling

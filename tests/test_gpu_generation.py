@@ -199,3 +199,26 @@ def test_1_6b_full_batch_properties():
         single, _ = run_hip(arch, sd, x[i:i + 1], nz[:, i:i + 1], G, opts, dtype=torch.bfloat16, model=model)
         u, v = single.hypotheses[0][0].seq.float()[P:], a.hypotheses[i][0].seq.float()[P:]
         assert torch.nn.functional.cosine_similarity(u, v, dim=-1).min() >= BF16_COS
+
+
+def test_graph_replay_equals_eager(monkeypatch):
+    """On a non-default stream the denoising loop is recorded into a graph once per active-document count and
+    replayed; the outputs must equal the eager launches bit for bit, also when documents leave the batch
+    (ragged prompts -> different finishing steps -> several recorded loops)."""
+    arch = "mini_two_tower_diffusion_lcm"
+    lens = [2, 4, 3, 4]
+    cfg, sd, x, nz = make_problem(arch, 4, 4, 3, prompt_lens=lens)
+    opts = dict(DEFAULT_OPTS, inference_timesteps=10)
+    stream = torch.cuda.Stream()
+    monkeypatch.setenv("LCMHIP_GRAPH", "0")
+    with torch.cuda.stream(stream):
+        eager, model = run_hip(arch, sd, x, nz, 3, opts, prompt_lens=lens)
+    monkeypatch.setenv("LCMHIP_GRAPH", "1")
+    with torch.cuda.stream(stream):
+        graph, _ = run_hip(arch, sd, x, nz, 3, opts, prompt_lens=lens, model=model)
+        again, _ = run_hip(arch, sd, x, nz, 3, opts, prompt_lens=lens, model=model)     # replays of cached graphs
+    for he, hg, ha in zip(eager.hypotheses, graph.hypotheses, again.hypotheses):
+        assert torch.equal(he[0].seq, hg[0].seq) and torch.equal(he[0].seq, ha[0].seq)
+    ref = run_oracle(cfg, sd, x, nz, 3, opts, prompt_lens=lens)
+    worst, cos = compare(graph.hypotheses, ref, sd)
+    assert worst <= FP32_MAX_ABS and cos >= FP32_COS, (worst, cos)
