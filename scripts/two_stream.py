@@ -21,9 +21,12 @@ def run(K):
     per = B // K
     outs = [None] * K
     def work(i):
+      try:
         with torch.cuda.stream(streams[i]):
             outs[i] = gens[i](EmbeddingsBatch(prompts[i * per:(i + 1) * per], None), max_gen_len=G,
                               noise=noise[:, i * per:(i + 1) * per].contiguous())
+      except Exception as e:
+        import traceback; traceback.print_exc()
     def once():
         ts = [threading.Thread(target=work, args=(i,)) for i in range(K)]
         for t in ts: t.start()
