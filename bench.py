@@ -227,7 +227,7 @@ def main():
             "value": round(generated / (elapsed / args.steps), 2), "unit": "sentence-embeddings/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"headline config: {args.arch}, random-init, {B} docs/GPU x {P} prompt + {G} generated "
+            "config": {"workload": f"config 3: {args.arch}, random-init, {B} docs/GPU x {P} prompt + {G} generated "
                                    f"sentences, 40 requested = 50 executed DDIM steps, CFG w=3 rescale=0.7",
                        "global_batch": world * B, "prompt_len": P, "gen_len": G, "executed_ddim_steps": 50,
                        "parallelism": f"dp{world} by document, one all-gather of outputs"},
