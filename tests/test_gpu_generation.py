@@ -9,6 +9,7 @@ import pytest
 import torch
 
 from lcm.inference.two_tower_diffusion_lcm import DiffusionLCMGeneratorOptions
+import oracle as oracle_mod
 from parity_utils import DEFAULT_OPTS, compare, make_problem, run_hip, run_oracle
 
 pytestmark = pytest.mark.gpu
@@ -248,3 +249,66 @@ def test_7b_arch_runs_and_matches_batch_of_one():
     one, _ = run_hip(arch, None, x[2:3], nz[:, 2:3], G, opts, dtype=torch.bfloat16, model=model)
     u, v = one.hypotheses[0][0].seq.float()[P:], a.hypotheses[2][0].seq.float()[P:]
     assert torch.nn.functional.cosine_similarity(u, v, dim=-1).min() >= BF16_COS
+
+
+def test_single_sentence_prompt_and_length_asserts():
+    """A one-sentence prompt has nothing to prefill (reference generator.py:244-259 logs and skips); the length
+    assertions of the reference (lcm/inference/lcm/generator.py:161-172) are kept."""
+    arch = "mini_two_tower_diffusion_lcm"
+    cfg, sd, x, nz = make_problem(arch, 3, 1, 3)
+    opts = dict(DEFAULT_OPTS, inference_timesteps=10)
+    ref = run_oracle(cfg, sd, x, nz, 3, opts)
+    out, model = run_hip(arch, sd, x, nz, 3, opts)
+    worst, cos = compare(out.hypotheses, ref, sd, start=1)
+    assert worst <= FP32_MAX_ABS and cos >= FP32_COS, (worst, cos)
+    with pytest.raises(AssertionError, match="Generator can generate up to"):
+        run_hip(arch, sd, x, nz, 1000, opts, model=model)
+    from lcm.inference.two_tower_diffusion_lcm import DiffusionLCMGeneratorOptions, TwoTowerDiffusionLCMGenerator
+    with pytest.raises(AssertionError, match="min_seq_len"):
+        TwoTowerDiffusionLCMGenerator(model, DiffusionLCMGeneratorOptions(min_seq_len=0))
+
+
+def test_min_gen_len_repetition_stop_and_eos_token_kept():
+    """Stopping rules of finalize_step (reference generator.py:331-372, 425-440): an EOS hit before min_gen_len is
+    ignored; a repetition threshold of -1 stops every document at its first allowed step; include_eos_token keeps
+    the stopping embedding in a trimmed hypothesis."""
+    arch = "mini_two_tower_diffusion_lcm"
+    cfg, sd, x, nz = make_problem(arch, 2, 2, 5)
+    base = dict(DEFAULT_OPTS, inference_timesteps=5)
+    free = run_oracle(cfg, sd, x, nz, 5, base)
+    eos = free[0][0].seq[2].clone()                       # document 0's first generated sentence
+    for extra, min_len in [(dict(eos_threshold=0.999, trim_hypotheses=True), 1),
+                           (dict(eos_threshold=0.999, trim_hypotheses=True), 3),
+                           (dict(eos_threshold=0.999, trim_hypotheses=True, include_eos_token=True), 1),
+                           (dict(stop_on_repetition_cosine_threshold=-1.0, min_seq_len=2), None)]:
+        o = dict(base, **extra)
+        kw = {} if min_len is None else dict(min_gen_len=min_len)
+        model_o = oracle_mod.OracleTwoTower(cfg, sd)
+        gen_o = oracle_mod.OracleGenerator(model_o, oracle_mod.GenOptions(**o), eos_vec=eos)
+        ref = gen_o(x, max_gen_len=5, noise=nz, **kw)
+        from lcm.datasets.batch import EmbeddingsBatch
+        from lcm.inference.two_tower_diffusion_lcm import DiffusionLCMGeneratorOptions, TwoTowerDiffusionLCMGenerator
+        from lcm.models.two_tower_diffusion_lcm import create_two_tower_diffusion_lcm_model
+        from parity_utils import mini_config
+        model = create_two_tower_diffusion_lcm_model(mini_config(), device="cuda:0", dtype=torch.float32)
+        model.load_state_dict(sd)
+        gen = TwoTowerDiffusionLCMGenerator(model, DiffusionLCMGeneratorOptions(**o), eos_vec=eos.cuda())
+        out = gen(EmbeddingsBatch(x.cuda(), None), max_gen_len=5, noise=nz.cuda(), **kw)
+        assert [h[0].seq.shape[0] for h in out.hypotheses] == [h[0].seq.shape[0] for h in ref], (extra, min_len)
+        worst, cos = compare(out.hypotheses, ref, sd)
+        assert worst <= FP32_MAX_ABS and cos >= FP32_COS, (extra, worst, cos)
+
+
+def test_session_capacity_is_checked():
+    """Appending beyond the session's context capacity is an error, not an out-of-bounds write."""
+    from lcm.datasets.batch import EmbeddingsBatch
+    from lcm.models.two_tower_diffusion_lcm import create_two_tower_diffusion_lcm_model
+    from lcm.nn.incremental_state import LCMIncrementalStateBag
+    from parity_utils import mini_config
+    model = create_two_tower_diffusion_lcm_model(mini_config(), device="cuda:0", dtype=torch.float32)
+    model.prep_for_denoising(DiffusionLCMGeneratorOptions(inference_timesteps=5))
+    bag = LCMIncrementalStateBag(4)
+    model.encode(EmbeddingsBatch(torch.randn(2, 3, 1024, device="cuda"), None), bag)
+    with pytest.raises(RuntimeError, match="max_ctx"):
+        model.encode(EmbeddingsBatch(torch.randn(2, 2, 1024, device="cuda"), None), bag)
+    model.release_session(bag.session)
