@@ -312,3 +312,34 @@ def test_session_capacity_is_checked():
     with pytest.raises(RuntimeError, match="max_ctx"):
         model.encode(EmbeddingsBatch(torch.randn(2, 2, 1024, device="cuda"), None), bag)
     model.release_session(bag.session)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_stopping_patterns(seed):
+    """Ragged prompts plus an EOS vector that random documents hit at random steps: rows leave the batch one by one
+    (slot-map updates, a recorded loop per active count on a non-default stream); lengths and embeddings must follow
+    the oracle throughout."""
+    arch = "mini_two_tower_diffusion_lcm"
+    g = torch.Generator().manual_seed(100 + seed)
+    B, P, G = 7, 4, 6
+    lens = torch.randint(1, P + 1, (B,), generator=g).tolist()
+    lens[int(torch.randint(0, B, (1,), generator=g))] = P
+    cfg, sd, x, nz = make_problem(arch, B, P, G, seed=seed, prompt_lens=lens)
+    opts = dict(DEFAULT_OPTS, inference_timesteps=5)
+    free = run_oracle(cfg, sd, x, nz, G, opts, prompt_lens=lens)
+    # an EOS direction close to several generated sentences: their mean
+    picks = [free[i][0].seq[lens[i] + int(torch.randint(0, G, (1,), generator=g))] for i in range(B)]
+    eos = torch.stack(picks).mean(0)
+    sims = torch.cat([torch.nn.functional.cosine_similarity(eos[None], free[i][0].seq[lens[i]:]) for i in range(B)])
+    srt = sims.sort().values
+    k = int(0.6 * len(srt))
+    thr = float((srt[k] + srt[k + 1]) / 2)     # ~40 % of the free-running sentences would stop; no value sits on the threshold
+    o = dict(opts, eos_threshold=thr, trim_hypotheses=bool(seed % 2))
+    ref = run_oracle(cfg, sd, x, nz, G, o, prompt_lens=lens, eos_vec=eos)
+    with torch.cuda.stream(torch.cuda.Stream()):
+        out, _ = run_hip(arch, sd, x, nz, G, o, prompt_lens=lens, eos_vec=eos)
+    got, want = [h[0].seq.shape[0] for h in out.hypotheses], [h[0].seq.shape[0] for h in ref]
+    assert got == want
+    assert len(set(want)) > 1                                       # documents really finished at different steps
+    worst, cos = compare(out.hypotheses, ref, sd)
+    assert worst <= FP32_MAX_ABS and cos >= FP32_COS, (worst, cos)
