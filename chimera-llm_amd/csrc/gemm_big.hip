@@ -11,6 +11,8 @@
 // t + 1 runs while the matrix cores consume tile t; one barrier per K tile.  (A three-stage variant with one
 // workgroup per CU and a counted vmcnt across a bare s_barrier measured 20-25 % slower than two stages with two
 // workgroups per CU.)
+#include <cstdlib>
+
 #include "common.h"
 #include "gemm_epilogue.h"
 
@@ -19,19 +21,24 @@ namespace lcmhip {
 namespace {
 constexpr int kBM = 128, kBN = 128;
 constexpr int kRowB = 128;                      // bytes of K per tile row and stage (64 bf16)
-constexpr int kStageB = (kBM + kBN) * kRowB;    // 32 KiB
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 }  // namespace
 
-template <int EPI>
-__global__ __launch_bounds__(256) void k_gemm_big(GemmArgs p) {
+// WMV wave rows: the tile is (64 * WMV) rows x 128 weight rows, 2 * WMV waves of 64 x 64 each.
+template <int EPI, int WMV>
+__global__ __launch_bounds__(128 * WMV) void k_gemm_big(GemmArgs p) {
     constexpr bool DUAL = (EPI == LCMHIP_EPI_SWIGLU);
-    __shared__ __attribute__((aligned(1024))) char smem[2 * kStageB];
+    constexpr int BM = 64 * WMV, NWAVES = 2 * WMV;
+    constexpr int STAGE = (BM + kBN) * kRowB;
+    constexpr int NGRP = (BM + kBN) / 8 / NWAVES;   // 8-row groups each wave stages per K tile
+    constexpr int AGRP = BM / 8 / NWAVES;           // ... of which activation rows
+    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
-    const int m0 = blockIdx.z * kBM;
+    const int bx = blockIdx.x, bz = blockIdx.z;
+    const int m0 = bz * BM;
     const size_t kbytes = (size_t)p.K * 2;
     const int nk = (int)(kbytes / kRowB);
     const int kps = (nk + (int)gridDim.y - 1) / (int)gridDim.y;
@@ -44,34 +51,34 @@ __global__ __launch_bounds__(256) void k_gemm_big(GemmArgs p) {
     const int srow = lane >> 3;
     // swizzle: slot s of tile row r holds K piece s ^ ((r / 2) % 8).  Two consecutive rows share one 256-byte bank
     // line, so the 16 rows x one piece of a fragment read land on 16 distinct 16-byte bank groups.  For the rows
-    // this lane stages, r = 8 * (wid + 4 j) + srow, hence (r / 2) % 8 = 4 * (wid % 2) + srow / 2 for every j.
+    // this lane stages, r = 8 * (wid + NWAVES j) + srow, hence (r / 2) % 8 = 4 * (wid % 2) + srow / 2 for every j.
     const size_t piece_off = (size_t)(((lane & 7) ^ (4 * (wid & 1) + (srow >> 1))) * 16);
-    const char* src[8];
+    const char* src[NGRP];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int grp = wid + 4 * j;            // j < 4: activations, j >= 4: weights (wave-uniform)
-        if (j < 4) {
+    for (int j = 0; j < NGRP; ++j) {
+        const int grp = wid + NWAVES * j;       // j < AGRP: activations, else weights (wave-uniform)
+        if (j < AGRP) {
             int m = m0 + grp * 8 + srow;
             m = m < p.M ? m : p.M - 1;          // rows past the end repeat the last row; never stored
             src[j] = reinterpret_cast<const char*>(p.A) + (size_t)m * p.lda * 2 + piece_off;
         } else {
-            const int t = (grp - 16) * 8 + srow;   // weight row inside the tile, 0..127
+            const int t = (grp - BM / 8) * 8 + srow;   // weight row inside the tile, 0..127
             if constexpr (DUAL) {
                 // wave column wn' = t / 64 owns 32 gate rows followed by 32 inner rows of the same 32 outputs
                 const int wcol = t >> 6, rr = t & 63;
-                const size_t row = (size_t)blockIdx.x * (kBN / 2) + wcol * 32 + (rr & 31);
+                const size_t row = (size_t)bx * (kBN / 2) + wcol * 32 + (rr & 31);
                 src[j] = reinterpret_cast<const char*>(rr < 32 ? p.W : p.W2) + row * kbytes + piece_off;
             } else {
-                src[j] = reinterpret_cast<const char*>(p.W) + ((size_t)blockIdx.x * kBN + t) * kbytes + piece_off;
+                src[j] = reinterpret_cast<const char*>(p.W) + ((size_t)bx * kBN + t) * kbytes + piece_off;
             }
         }
     }
     auto stage = [&](int kt, int buf) {
         const size_t koff = (size_t)kt * kRowB;
-        char* dst = smem + buf * kStageB;
+        char* dst = smem + buf * STAGE;
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + koff), (lptr_t)(dst + (wid + 4 * j) * 1024), 16, 0, 0);
+        for (int j = 0; j < NGRP; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + koff), (lptr_t)(dst + (wid + NWAVES * j) * 1024), 16, 0, 0);
     };
 
     f32x4 acc[4][4];
@@ -84,7 +91,7 @@ __global__ __launch_bounds__(256) void k_gemm_big(GemmArgs p) {
     const int frow = lane & 15;
     const int fsw = (frow >> 1) & 7;   // tile row bases are multiples of 16
     const int x_row0 = wm * 64 + frow;
-    const int w_row0 = kBM + wn * 64 + frow;
+    const int w_row0 = BM + wn * 64 + frow;
 
     stage(k_begin, 0);
     for (int kt = k_begin; kt < k_end; ++kt) {
@@ -92,32 +99,38 @@ __global__ __launch_bounds__(256) void k_gemm_big(GemmArgs p) {
         // tile kt has landed for every wave, and every wave is done reading the other stage
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (kt + 1 < k_end) stage(kt + 1, buf ^ 1);
-        const char* base = smem + buf * kStageB;
+        const char* base = smem + buf * STAGE;
+        // all 16 fragments of the K tile first, then the 32 matrix-core instructions
+        bf16x8 w[2][4], x[2][4];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int slot = ((4 * ks + (lane >> 4)) ^ fsw) * 16;
-            bf16x8 w[4], x[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) w[t] = *reinterpret_cast<const bf16x8*>(base + (w_row0 + 16 * t) * kRowB + slot);
+            for (int t = 0; t < 4; ++t) w[ks][t] = *reinterpret_cast<const bf16x8*>(base + (w_row0 + 16 * t) * kRowB + slot);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) x[t] = *reinterpret_cast<const bf16x8*>(base + (x_row0 + 16 * t) * kRowB + slot);
+            for (int t = 0; t < 4; ++t) x[ks][t] = *reinterpret_cast<const bf16x8*>(base + (x_row0 + 16 * t) * kRowB + slot);
+        }
+        // the DMA of the next tile is issued behind this tile's fragment reads, not ahead of them
+        if (kt + 1 < k_end) stage(kt + 1, buf ^ 1);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
                 for (int tm = 0; tm < 4; ++tm)
-                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[tn], x[tm], acc[tn][tm], 0, 0, 0);
-        }
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ks][tn], x[ks][tm], acc[tn][tm], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
     }
 
-    gemm_epilogue<bf16_t, EPI, 4, 4>(p, acc, m0 + wm * 64, DUAL ? blockIdx.x * (kBN / 2) + wn * 32 : blockIdx.x * kBN + wn * 64,
+    gemm_epilogue<bf16_t, EPI, 4, 4>(p, acc, m0 + wm * 64, DUAL ? bx * (kBN / 2) + wn * 32 : bx * kBN + wn * 64,
                                      blockIdx.y, lane);
 }
 
 // K splits for the split-K (slab) form: enough workgroups for the chip, at least 8 K tiles per split, and the
 // splits divide the K tiles
 int gemm_big_splits(const GemmArgs& a, int max_splits) {
-    const int tiles = (a.N / kBN) * ((a.M + kBM - 1) / kBM);
+    const int tiles = (a.N / kBN) * ((a.M + kBM - 1) / kBM);   // counted in 128-row tiles
     const int nk = a.K / 64;
     int s = 1;
     while (tiles * s < 256 && nk % (s * 2) == 0 && nk / (s * 2) >= 8 && s * 2 <= (max_splits > 0 ? max_splits : 64)) s *= 2;
@@ -138,16 +151,19 @@ bool gemm_big_applicable(const GemmArgs& a, bool may_split) {
 // epi: LCMHIP_EPI_* or EPI_PARTIAL; splits >= 1 (only with EPI_PARTIAL); m_rows: rows the row tiles must cover
 int launch_gemm_big(const GemmArgs& a, int epi, int splits, int m_rows, hipStream_t st) {
     const int wrows = epi == LCMHIP_EPI_SWIGLU ? 2 * a.N : a.N;
+    // (256 x 128 tiles with 8 waves and one workgroup per CU measured 10-20 % slower than two 128 x 128 workgroups.)
     dim3 grid(wrows / kBN, splits, (m_rows + kBM - 1) / kBM), block(256);
+#define LCM_BIG(E) hipLaunchKernelGGL((k_gemm_big<E, 2>), grid, block, 0, st, a)
     switch (epi) {
-        case LCMHIP_EPI_STORE: hipLaunchKernelGGL((k_gemm_big<LCMHIP_EPI_STORE>), grid, block, 0, st, a); break;
-        case LCMHIP_EPI_STORE_F32: hipLaunchKernelGGL((k_gemm_big<LCMHIP_EPI_STORE_F32>), grid, block, 0, st, a); break;
-        case LCMHIP_EPI_RELU: hipLaunchKernelGGL((k_gemm_big<LCMHIP_EPI_RELU>), grid, block, 0, st, a); break;
-        case LCMHIP_EPI_SWIGLU: hipLaunchKernelGGL((k_gemm_big<LCMHIP_EPI_SWIGLU>), grid, block, 0, st, a); break;
-        case LCMHIP_EPI_RESID: hipLaunchKernelGGL((k_gemm_big<LCMHIP_EPI_RESID>), grid, block, 0, st, a); break;
-        case EPI_PARTIAL: hipLaunchKernelGGL((k_gemm_big<EPI_PARTIAL>), grid, block, 0, st, a); break;
+        case LCMHIP_EPI_STORE: LCM_BIG(LCMHIP_EPI_STORE); break;
+        case LCMHIP_EPI_STORE_F32: LCM_BIG(LCMHIP_EPI_STORE_F32); break;
+        case LCMHIP_EPI_RELU: LCM_BIG(LCMHIP_EPI_RELU); break;
+        case LCMHIP_EPI_SWIGLU: LCM_BIG(LCMHIP_EPI_SWIGLU); break;
+        case LCMHIP_EPI_RESID: LCM_BIG(LCMHIP_EPI_RESID); break;
+        case EPI_PARTIAL: LCM_BIG(EPI_PARTIAL); break;
         default: return fail(LCMHIP_ERR_INVALID, "gemm: unknown epilogue");
     }
+#undef LCM_BIG
     LCM_HIP_CHECK(hipGetLastError());
     return LCMHIP_OK;
 }
