@@ -765,26 +765,37 @@ static int append_impl(lcmhip_session* s, const float* x, int32_t n_tokens, int3
     lcmhip_model* m = s->model;
     const lcmhip_model_desc& d = m->desc;
     const lcmhip_tower_desc& tc = d.context;
-    const int dm = d.model_dim, D = d.sonar_dim, n = s->n_active;
+    const int dm = d.model_dim, D = d.sonar_dim;
     const size_t es = dtype_size(d.dtype);
     const size_t self_layer = (size_t)s->max_batch * s->cap * dm * es;
     const size_t cross_layer = (size_t)s->max_batch * (s->cap + 1) * dm * es;
-    const int per_chunk = std::max(1, s->chunk_rows / n);
+    // One pass handles at most chunk_rows rows.  Long appends (prompt prefill) are cut by DOCUMENT first, so that a
+    // pass sees long causal query blocks (matrix-core attention, large GEMMs); only a single document longer than
+    // a pass is cut by position.  Short appends for many documents (generation steps) go in one pass.
+    const int n_total = s->n_active;
+    int doc_group = n_total;
+    if ((int64_t)n_total * n_tokens > s->chunk_rows && n_tokens >= 16) doc_group = std::max(1, s->chunk_rows / n_tokens);
+    const int n_out_pos = (bo && bo->all) ? n_tokens : 1;
 
+    for (int d0 = 0; d0 < n_total; d0 += doc_group) {
+    const int n = std::min(doc_group, n_total - d0);          // documents of this pass
+    const int per_chunk = std::max(1, s->chunk_rows / n);
+    const float* xg = x + (size_t)d0 * n_tokens * D;
+    const int32_t* slots = s->slot_map + d0;
     for (int j0 = 0; j0 < n_tokens; j0 += per_chunk) {
         const int sc = std::min(per_chunk, n_tokens - j0);
         const int R = n * sc;
         const int pos0 = s->ctx_len + j0;
-        hipLaunchKernelGGL(k_make_rows, dim3((R + 255) / 256), dim3(256), 0, st, s->slot_map, s->pos_rows, s->self_rows,
+        hipLaunchKernelGGL(k_make_rows, dim3((R + 255) / 256), dim3(256), 0, st, slots, s->pos_rows, s->self_rows,
                            s->cross_rows, R, sc, pos0, s->cap);
         LCM_HIP_CHECK(hipGetLastError());
         {
             ProfScope ps(&s->prof, "ctx.normalize", R * (double)D * (4.0 + es), 0.0, st);
             if (d.dtype == LCMHIP_BF16)
-                hipLaunchKernelGGL((k_normalize_gather<bf16_t>), dim3(R), dim3(128), 0, st, x, (const bf16_t*)m->center,
+                hipLaunchKernelGGL((k_normalize_gather<bf16_t>), dim3(R), dim3(128), 0, st, xg, (const bf16_t*)m->center,
                                    (const bf16_t*)m->scale, (bf16_t*)s->act_in, D, sc, n_tokens, j0, (normalized || !m->center) ? 0 : 1, d.embed_scale);
             else
-                hipLaunchKernelGGL((k_normalize_gather<float>), dim3(R), dim3(128), 0, st, x, (const float*)m->center,
+                hipLaunchKernelGGL((k_normalize_gather<float>), dim3(R), dim3(128), 0, st, xg, (const float*)m->center,
                                    (const float*)m->scale, (float*)s->act_in, D, sc, n_tokens, j0, (normalized || !m->center) ? 0 : 1, d.embed_scale);
             LCM_HIP_CHECK(hipGetLastError());
         }
@@ -804,7 +815,7 @@ static int append_impl(lcmhip_session* s, const float* x, int32_t n_tokens, int3
             }
             {
                 ProfScope ps(&s->prof, "ctx.attn", 2.0 * n * (double)(pos0 + sc) * dm * es, 4.0 * R * (double)(pos0 + sc) * dm, st);
-                LCM_TRY(launch_attention(s->act_q, s->self_k + l * self_layer, s->self_v + l * self_layer, s->slot_map, s->act_o,
+                LCM_TRY(launch_attention(s->act_q, s->self_k + l * self_layer, s->self_v + l * self_layer, slots, s->act_o,
                                          n, sc, tc.num_heads, s->cap, pos0, 1, d.dtype, st));
             }
             LCM_TRY(gemm(s, "ctx.attn_out", s->act_o, dm, L.sa.o, nullptr, nullptr, s->xres, dm, R, LCMHIP_EPI_RESID, st));
@@ -831,14 +842,17 @@ static int append_impl(lcmhip_session* s, const float* x, int32_t n_tokens, int3
         if (bo && bo->out && (bo->all || j0 + sc == n_tokens)) {
             LCM_TRY(gemm(s, "base.postnet", s->act_a, dm, m->postnet, nullptr, nullptr, s->f32tmp, D, R, LCMHIP_EPI_STORE_F32, st));
             ProfScope ps(&s->prof, "base.out", R * (double)D * 8.0, 0.0, st);
+            float* g_out = bo->out + (size_t)d0 * n_out_pos * D;
+            const float* g_noise = bo->noise ? bo->noise + (size_t)d0 * n_out_pos * D : nullptr;
             if (d.dtype == LCMHIP_BF16)
-                hipLaunchKernelGGL((k_base_out<bf16_t>), dim3(R), dim3(128), 0, st, s->f32tmp, bo->noise, (const bf16_t*)m->center,
-                                   (const bf16_t*)m->scale, bo->out, D, sc, n_tokens, j0, bo->all, bo->temperature);
+                hipLaunchKernelGGL((k_base_out<bf16_t>), dim3(R), dim3(128), 0, st, s->f32tmp, g_noise, (const bf16_t*)m->center,
+                                   (const bf16_t*)m->scale, g_out, D, sc, n_tokens, j0, bo->all, bo->temperature);
             else
-                hipLaunchKernelGGL((k_base_out<float>), dim3(R), dim3(128), 0, st, s->f32tmp, bo->noise, (const float*)m->center,
-                                   (const float*)m->scale, bo->out, D, sc, n_tokens, j0, bo->all, bo->temperature);
+                hipLaunchKernelGGL((k_base_out<float>), dim3(R), dim3(128), 0, st, s->f32tmp, g_noise, (const float*)m->center,
+                                   (const float*)m->scale, g_out, D, sc, n_tokens, j0, bo->all, bo->temperature);
             LCM_HIP_CHECK(hipGetLastError());
         }
+    }
     }
     s->ctx_len += n_tokens;
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), s->d_cross_keys, s->ctx_len + 1);
