@@ -52,32 +52,6 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-#ifndef LCM_NT_WEIGHTS
-#define LCM_NT_WEIGHTS 0   // 1: weights (read once per launch) are loaded with the non-temporal policy
-#endif
-#if LCM_NT_WEIGHTS
-#define LCM_WLOAD(p) __builtin_nontemporal_load(p)
-#else
-#define LCM_WLOAD(p) (*(p))
-#endif
-// timing-only address remaps (LCM_ABLATE 4, 5): pretend the operand is stored chunk-major, i.e. the 512-byte
-// pieces of one K chunk of consecutive rows are contiguous (row pitch 512 B, chunk pitch rows * 512 B)
-#if LCM_ABLATE == 4 || LCM_ABLATE == 5
-#define LCM_CM_W(rowptr, base, off) cm_addr(rowptr, reinterpret_cast<const char*>(base), kbytes, (size_t)p.N, off)
-#else
-#define LCM_CM_W(rowptr, base, off) ((rowptr) + (off))
-#endif
-#if LCM_ABLATE == 5
-#define LCM_CM_A(rowptr, off) cm_addr(rowptr, reinterpret_cast<const char*>(p.A), a_stride, (size_t)p.M, off)
-#else
-#define LCM_CM_A(rowptr, off) ((rowptr) + (off))
-#endif
-#ifndef LCM_DEPTH2
-#define LCM_DEPTH2 0   // 1: two chunks of loads in flight per workgroup (measured slower: the tile is bound by LDS and L1 intake, not by latency); 0: one
-#endif
-#ifndef LCM_ABLATE
-#define LCM_ABLATE 0   // 1: no LDS reads / MFMA; 2: no global loads after the first chunk (timing studies only)
-#endif
 constexpr int kChunkBytes = 512;             // bytes of K per tile row per chunk
 constexpr int kRowBytes = kChunkBytes + 16;  // padded LDS row
 
@@ -107,9 +81,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs p) {
     const int c_begin = blockIdx.y * cps;
     const int c_end = min(nchunks, c_begin + cps);
 
-    // Lane (r0 = tid / 32, c = tid % 32) moves the 16-byte piece c of tile rows r0, r0 + 8, r0 + 16, ...:
+    // Lane (r0 = tid / 32, c = tid % 32) moves the 16-byte piece c of tile rows r0, r0 + RP, r0 + 2 RP, ...:
     // 32 consecutive lanes cover one 512-byte row segment.  Row addresses are recomputed from two
-    // scalars per operand (no per-piece pointer arrays, which the compiler would keep in scratch).
+    // scalars per operand (no per-piece pointer arrays).
     constexpr int NA = BM / RP, NW = BNR / RP;
     const int r0 = tid >> 5;
     const size_t col_off = (size_t)(tid & 31) * 16 + (size_t)c_begin * kChunkBytes;
@@ -124,52 +98,37 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs p) {
         w_base = reinterpret_cast<const char*>(p.W) + (size_t)(blockIdx.x * BNR + r0) * kbytes + col_off;
     }
     char* lds_dst = smem + r0 * kRowBytes + (tid & 31) * 16;
-    // timing studies only: address of the same piece if the operand were stored chunk-major
-    auto cm_addr = [&](const char* rowptr, const char* base, size_t pitch, size_t rows, size_t off) {
-        const size_t row = (size_t)(rowptr - base) / pitch;
-        return base + row * 512 + (off / 512 + c_begin) * rows * 512 + (tid & 31) * 16;
-    };
-    (void)cm_addr;
 
-    // Two register sets: while one chunk is being consumed from LDS, the loads of the next TWO chunks are
-    // in flight (vector-memory loads retire in order, so waiting for the older set leaves the newer
-    // one outstanding).  Single-chunk splits use only the first set.
-    u32x4 ra0[NA], rw0[NW], ra1[NA], rw1[NW];
-#define LCM_LOAD_CHUNK(OFF, RA, RW)                                                                      \
+    // One register set: while a chunk is consumed from LDS the next chunk's loads are in flight.  (A second set,
+    // i.e. two chunks in flight, measured slower: the tile is bound by LDS and L1 intake, not by load latency;
+    // so did non-temporal weight loads, because both row tiles read every weight row.)
+    u32x4 ra[NA], rw[NW];
+#define LCM_LOAD_CHUNK(OFF)                                                                              \
     {                                                                                                    \
         const size_t off_ = (OFF);                                                                       \
         _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                 \
             int m = m0 + r0 + RP * i;                                                                    \
             m = m < p.M ? m : p.M - 1;                                                                   \
-            RA[i] = *reinterpret_cast<const u32x4*>(LCM_CM_A(a_base + (size_t)m * a_stride, off_));      \
+            ra[i] = *reinterpret_cast<const u32x4*>(a_base + (size_t)m * a_stride + off_);               \
         }                                                                                                \
         _Pragma("unroll") for (int i = 0; i < NW; ++i) {                                                 \
             if constexpr (DUAL) {                                                                        \
-                /* tile row 8i + r0 belongs to wave (8i) / WR; a wave's first WR/2 rows = gate, rest = inner */ \
+                /* tile row RP i + r0 belongs to wave (RP i) / WR; a wave's first WR/2 rows = gate, rest = inner */ \
                 const int grp = (RP * i) / WR, rr = (RP * i) % WR;                                       \
                 const char* b = (rr < WR / 2 ? w_base : w2_base) + (size_t)(grp * (WR / 2) + (rr % (WR / 2))) * kbytes; \
-                RW[i] = LCM_WLOAD(reinterpret_cast<const u32x4*>(LCM_CM_W(b, (rr < WR / 2 ? p.W : p.W2), off_)));                    \
+                rw[i] = *reinterpret_cast<const u32x4*>(b + off_);                                       \
             } else {                                                                                     \
-                RW[i] = LCM_WLOAD(reinterpret_cast<const u32x4*>(LCM_CM_W(w_base + (size_t)(RP * i) * kbytes, p.W, off_))); \
+                rw[i] = *reinterpret_cast<const u32x4*>(w_base + (size_t)(RP * i) * kbytes + off_);      \
             }                                                                                            \
         }                                                                                                \
     }
-#if LCM_ABLATE >= 3
-    u32x4 sink_ = {0u, 0u, 0u, 0u};
-#define LCM_STORE_CHUNK(RA, RW)                                                                          \
-    {                                                                                                    \
-        _Pragma("unroll") for (int i = 0; i < NA; ++i) sink_ ^= RA[i];                                   \
-        _Pragma("unroll") for (int i = 0; i < NW; ++i) sink_ ^= RW[i];                                   \
-    }
-#else
-#define LCM_STORE_CHUNK(RA, RW)                                                                          \
+#define LCM_STORE_CHUNK()                                                                                \
     {                                                                                                    \
         _Pragma("unroll") for (int i = 0; i < NA; ++i)                                                   \
-            *reinterpret_cast<u32x4*>(lds_dst + (RP * i) * kRowBytes) = RA[i];                           \
+            *reinterpret_cast<u32x4*>(lds_dst + (RP * i) * kRowBytes) = ra[i];                           \
         _Pragma("unroll") for (int i = 0; i < NW; ++i)                                                   \
-            *reinterpret_cast<u32x4*>(lds_dst + (BM + RP * i) * kRowBytes) = RW[i];                      \
+            *reinterpret_cast<u32x4*>(lds_dst + (BM + RP * i) * kRowBytes) = rw[i];                      \
     }
-#endif
 
     f32x4 acc[TN][2];
 #pragma unroll
@@ -181,9 +140,15 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs p) {
     const int fk = (lane >> 4) * Mma<T>::kLaneBytes;
     const char* w_frag = smem + (BM + wn * WR + frow) * kRowBytes + fk;
     const char* x_frag = smem + (wm * 32 + frow) * kRowBytes + fk;
-    auto consume = [&]() {
+
+    LCM_LOAD_CHUNK(0);   // every split owns at least one chunk (see make_plan)
+    for (int ch = c_begin; ch < c_end; ++ch) {
+        if (ch != c_begin) __syncthreads();   // previous chunk fully consumed before it is overwritten
+        LCM_STORE_CHUNK();
+        __syncthreads();
+        if (ch + 1 < c_end) LCM_LOAD_CHUNK((size_t)(ch + 1 - c_begin) * kChunkBytes);
 #pragma unroll 2
-        for (int ks = 0; ks < ((LCM_ABLATE == 1 || LCM_ABLATE >= 3) ? 0 : KSTEPS); ++ks) {
+        for (int ks = 0; ks < KSTEPS; ++ks) {
             const int kb = ks * KSTEP_BYTES;
             typename Mma<T>::Frag w[TN], x[2];
 #pragma unroll
@@ -195,37 +160,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs p) {
 #pragma unroll
                 for (int tm = 0; tm < 2; ++tm) acc[tn][tm] = Mma<T>::mma(w[tn], x[tm], acc[tn][tm]);
         }
-    };
-
-#if LCM_ABLATE >= 3
-#define __syncthreads() ((void)0)
-#endif
-    const int nloc = c_end - c_begin;   // >= 1: every split owns at least one chunk (see make_plan)
-    LCM_LOAD_CHUNK(0, ra0, rw0);
-    if (LCM_DEPTH2 && nloc > 1) LCM_LOAD_CHUNK((size_t)kChunkBytes, ra1, rw1);
-    for (int c = 0; c < nloc; c += (LCM_DEPTH2 ? 2 : 1)) {
-        if (c != 0) __syncthreads();   // previous chunk fully consumed before it is overwritten
-        LCM_STORE_CHUNK(ra0, rw0);
-        __syncthreads();
-#if LCM_ABLATE != 2
-        if (c + (LCM_DEPTH2 ? 2 : 1) < nloc) LCM_LOAD_CHUNK((size_t)(c + (LCM_DEPTH2 ? 2 : 1)) * kChunkBytes, ra0, rw0);
-#endif
-        consume();
-        if (LCM_DEPTH2 && c + 1 < nloc) {
-            __syncthreads();
-            LCM_STORE_CHUNK(ra1, rw1);
-            __syncthreads();
-#if LCM_ABLATE != 2
-            if (c + 3 < nloc) LCM_LOAD_CHUNK((size_t)(c + 3) * kChunkBytes, ra1, rw1);
-#endif
-            consume();
-        }
     }
+#undef LCM_LOAD_CHUNK
+#undef LCM_STORE_CHUNK
 
-#if LCM_ABLATE >= 3
-#undef __syncthreads
-    if ((sink_.x ^ sink_.y ^ sink_.z ^ sink_.w) == 0x12345678u) acc[0][0][0] = 1.f;   // keeps the loads alive
-#endif
     // ---- epilogue: lane holds 4 consecutive columns of row m for each (tn, tm)
     gemm_epilogue<T, EPI, 2, TN>(p, acc, m0 + wm * 32, DUAL ? blockIdx.x * (BNR / 2) + wn * (WR / 2) : blockIdx.x * BNR + wn * WR,
                                  blockIdx.y, lane);
@@ -294,7 +232,7 @@ struct Plan {
 };
 
 static int tall_mode() {
-    static const int v = [] { const char* e = getenv("LCMHIP_TALL"); return e ? atoi(e) : 2; }();   // 0: 64 x 64 tiles only; 1: 128 x 64 with 4 waves; 2 (default): with 8 waves
+    static const int v = [] { const char* e = getenv("LCMHIP_TALL"); return e ? atoi(e) : 1; }();   // 0: 64 x 64 tiles only; 1 (default): 128 x 64 tiles with 8 waves for more than 64 rows
     return v;
 }
 
@@ -305,8 +243,7 @@ static Plan make_plan(const GemmArgs& a, bool may_split) {
     Plan pl{};
     if (rows <= 32 && wrows % 256 == 0) { pl.wm = 1; pl.wn = 4; pl.tn = 4; }         // 32 x 256
     else if (rows <= 64 && wrows % 128 == 0 && wrows >= 128 * 192) { pl.wm = 2; pl.wn = 2; pl.tn = 4; }   // 64 x 128
-    else if (rows > 64 && tall_mode() == 1) { pl.wm = 4; pl.wn = 1; pl.tn = 4; }      // 128 x 64, 4 waves
-    else if (rows > 64 && tall_mode() == 2) { pl.wm = 4; pl.wn = 2; pl.tn = 2; }      // 128 x 64, 8 waves: every weight row read by one workgroup
+    else if (rows > 64 && tall_mode() != 0) { pl.wm = 4; pl.wn = 2; pl.tn = 2; }      // 128 x 64, 8 waves: every weight row read by one workgroup
     else { pl.wm = 2; pl.wn = 2; pl.tn = 2; }                                        // 64 x 64, two per CU
     const int bm = 32 * pl.wm, bnr = 16 * pl.tn * pl.wn;
     pl.n_tiles = wrows / bnr;
@@ -350,7 +287,6 @@ template <typename T>
 static int launch_plan(const GemmArgs& a, const Plan& pl, int epi, hipStream_t st) {
     if (pl.wm == 1) return launch_cfg<T, 1, 4, 4>(a, pl, epi, st);
     if (pl.wm == 4 && pl.wn == 2) return launch_cfg<T, 4, 2, 2>(a, pl, epi, st);
-    if (pl.wm == 4) return launch_cfg<T, 4, 1, 4>(a, pl, epi, st);
     if (pl.tn == 4) return launch_cfg<T, 2, 2, 4>(a, pl, epi, st);
     return launch_cfg<T, 2, 2, 2>(a, pl, epi, st);
 }
