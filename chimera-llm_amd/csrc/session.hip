@@ -778,81 +778,81 @@ static int append_impl(lcmhip_session* s, const float* x, int32_t n_tokens, int3
     const int n_out_pos = (bo && bo->all) ? n_tokens : 1;
 
     for (int d0 = 0; d0 < n_total; d0 += doc_group) {
-    const int n = std::min(doc_group, n_total - d0);          // documents of this pass
-    const int per_chunk = std::max(1, s->chunk_rows / n);
-    const float* xg = x + (size_t)d0 * n_tokens * D;
-    const int32_t* slots = s->slot_map + d0;
-    for (int j0 = 0; j0 < n_tokens; j0 += per_chunk) {
-        const int sc = std::min(per_chunk, n_tokens - j0);
-        const int R = n * sc;
-        const int pos0 = s->ctx_len + j0;
-        hipLaunchKernelGGL(k_make_rows, dim3((R + 255) / 256), dim3(256), 0, st, slots, s->pos_rows, s->self_rows,
-                           s->cross_rows, R, sc, pos0, s->cap);
-        LCM_HIP_CHECK(hipGetLastError());
-        {
-            ProfScope ps(&s->prof, "ctx.normalize", R * (double)D * (4.0 + es), 0.0, st);
-            if (d.dtype == LCMHIP_BF16)
-                hipLaunchKernelGGL((k_normalize_gather<bf16_t>), dim3(R), dim3(128), 0, st, xg, (const bf16_t*)m->center,
-                                   (const bf16_t*)m->scale, (bf16_t*)s->act_in, D, sc, n_tokens, j0, (normalized || !m->center) ? 0 : 1, d.embed_scale);
-            else
-                hipLaunchKernelGGL((k_normalize_gather<float>), dim3(R), dim3(128), 0, st, xg, (const float*)m->center,
-                                   (const float*)m->scale, (float*)s->act_in, D, sc, n_tokens, j0, (normalized || !m->center) ? 0 : 1, d.embed_scale);
+        const int n = std::min(doc_group, n_total - d0);          // documents of this pass
+        const int per_chunk = std::max(1, s->chunk_rows / n);
+        const float* xg = x + (size_t)d0 * n_tokens * D;
+        const int32_t* slots = s->slot_map + d0;
+        for (int j0 = 0; j0 < n_tokens; j0 += per_chunk) {
+            const int sc = std::min(per_chunk, n_tokens - j0);
+            const int R = n * sc;
+            const int pos0 = s->ctx_len + j0;
+            hipLaunchKernelGGL(k_make_rows, dim3((R + 255) / 256), dim3(256), 0, st, slots, s->pos_rows, s->self_rows,
+                               s->cross_rows, R, sc, pos0, s->cap);
             LCM_HIP_CHECK(hipGetLastError());
-        }
-        LCM_TRY(gemm(s, "ctx.frontend", s->act_in, D, m->pre_linear, nullptr, nullptr, s->xres, dm, R, LCMHIP_EPI_STORE_F32, st));
-        if (tc.pos_kind == LCMHIP_POS_LEARNED) LCM_TRY(launch_add_pos(s->xres, m->pos_table, s->pos_rows, R, dm, d.dtype, st));
-        for (int l = 0; l < tc.num_layers; ++l) {
-            const CtxLayer& L = m->ctx[l];
-            LCM_TRY(norm(s, "ctx.norm", s->xres, L.sa_norm, nullptr, nullptr, s->act_a, R, R, tc.norm_kind, nullptr, st));
-            LCM_TRY(gemm(s, "ctx.qkv", s->act_a, dm, L.sa.q, nullptr, nullptr, s->act_q, dm, R, LCMHIP_EPI_STORE, st));
-            LCM_TRY(gemm(s, "ctx.qkv", s->act_a, dm, L.sa.k, nullptr, nullptr, s->act_k, dm, R, LCMHIP_EPI_STORE, st));
-            LCM_TRY(gemm(s, "ctx.qkv", s->act_a, dm, L.sa.v, nullptr, nullptr, s->act_v, dm, R, LCMHIP_EPI_STORE, st));
             {
-                ProfScope ps(&s->prof, "ctx.rope_store", 5.0 * R * dm * es, 0.0, st);
-                LCM_TRY(launch_rope_store(s->act_q, s->act_k, s->act_v, s->self_k + l * self_layer, s->self_v + l * self_layer,
-                                          s->self_rows, s->pos_rows, s->rope_cos, s->rope_sin, R, dm, s->cap,
-                                          tc.pos_kind == LCMHIP_POS_ROPE, d.dtype, st));
+                ProfScope ps(&s->prof, "ctx.normalize", R * (double)D * (4.0 + es), 0.0, st);
+                if (d.dtype == LCMHIP_BF16)
+                    hipLaunchKernelGGL((k_normalize_gather<bf16_t>), dim3(R), dim3(128), 0, st, xg, (const bf16_t*)m->center,
+                                       (const bf16_t*)m->scale, (bf16_t*)s->act_in, D, sc, n_tokens, j0, (normalized || !m->center) ? 0 : 1, d.embed_scale);
+                else
+                    hipLaunchKernelGGL((k_normalize_gather<float>), dim3(R), dim3(128), 0, st, xg, (const float*)m->center,
+                                       (const float*)m->scale, (float*)s->act_in, D, sc, n_tokens, j0, (normalized || !m->center) ? 0 : 1, d.embed_scale);
+                LCM_HIP_CHECK(hipGetLastError());
             }
-            {
-                ProfScope ps(&s->prof, "ctx.attn", 2.0 * n * (double)(pos0 + sc) * dm * es, 4.0 * R * (double)(pos0 + sc) * dm, st);
-                LCM_TRY(launch_attention(s->act_q, s->self_k + l * self_layer, s->self_v + l * self_layer, slots, s->act_o,
-                                         n, sc, tc.num_heads, s->cap, pos0, 1, d.dtype, st));
+            LCM_TRY(gemm(s, "ctx.frontend", s->act_in, D, m->pre_linear, nullptr, nullptr, s->xres, dm, R, LCMHIP_EPI_STORE_F32, st));
+            if (tc.pos_kind == LCMHIP_POS_LEARNED) LCM_TRY(launch_add_pos(s->xres, m->pos_table, s->pos_rows, R, dm, d.dtype, st));
+            for (int l = 0; l < tc.num_layers; ++l) {
+                const CtxLayer& L = m->ctx[l];
+                LCM_TRY(norm(s, "ctx.norm", s->xres, L.sa_norm, nullptr, nullptr, s->act_a, R, R, tc.norm_kind, nullptr, st));
+                LCM_TRY(gemm(s, "ctx.qkv", s->act_a, dm, L.sa.q, nullptr, nullptr, s->act_q, dm, R, LCMHIP_EPI_STORE, st));
+                LCM_TRY(gemm(s, "ctx.qkv", s->act_a, dm, L.sa.k, nullptr, nullptr, s->act_k, dm, R, LCMHIP_EPI_STORE, st));
+                LCM_TRY(gemm(s, "ctx.qkv", s->act_a, dm, L.sa.v, nullptr, nullptr, s->act_v, dm, R, LCMHIP_EPI_STORE, st));
+                {
+                    ProfScope ps(&s->prof, "ctx.rope_store", 5.0 * R * dm * es, 0.0, st);
+                    LCM_TRY(launch_rope_store(s->act_q, s->act_k, s->act_v, s->self_k + l * self_layer, s->self_v + l * self_layer,
+                                              s->self_rows, s->pos_rows, s->rope_cos, s->rope_sin, R, dm, s->cap,
+                                              tc.pos_kind == LCMHIP_POS_ROPE, d.dtype, st));
+                }
+                {
+                    ProfScope ps(&s->prof, "ctx.attn", 2.0 * n * (double)(pos0 + sc) * dm * es, 4.0 * R * (double)(pos0 + sc) * dm, st);
+                    LCM_TRY(launch_attention(s->act_q, s->self_k + l * self_layer, s->self_v + l * self_layer, slots, s->act_o,
+                                             n, sc, tc.num_heads, s->cap, pos0, 1, d.dtype, st));
+                }
+                LCM_TRY(gemm(s, "ctx.attn_out", s->act_o, dm, L.sa.o, nullptr, nullptr, s->xres, dm, R, LCMHIP_EPI_RESID, st));
+                LCM_TRY(norm(s, "ctx.norm", s->xres, L.ffn_norm, nullptr, nullptr, s->act_a, R, R, tc.norm_kind, nullptr, st));
+                LCM_TRY(ffn_in(s, "ctx.ffn_in", tc, L.ffn, s->act_a, R, st));
+                LCM_TRY(gemm(s, "ctx.ffn_out", s->act_h, tc.ffn_dim, L.ffn.out, nullptr, nullptr, s->xres, dm, R, LCMHIP_EPI_RESID, st));
             }
-            LCM_TRY(gemm(s, "ctx.attn_out", s->act_o, dm, L.sa.o, nullptr, nullptr, s->xres, dm, R, LCMHIP_EPI_RESID, st));
-            LCM_TRY(norm(s, "ctx.norm", s->xres, L.ffn_norm, nullptr, nullptr, s->act_a, R, R, tc.norm_kind, nullptr, st));
-            LCM_TRY(ffn_in(s, "ctx.ffn_in", tc, L.ffn, s->act_a, R, st));
-            LCM_TRY(gemm(s, "ctx.ffn_out", s->act_h, tc.ffn_dim, L.ffn.out, nullptr, nullptr, s->xres, dm, R, LCMHIP_EPI_RESID, st));
+            LCM_TRY(norm(s, "ctx.norm", s->xres, m->ctx_final, nullptr, nullptr, s->act_a, R, R, tc.norm_kind, nullptr, st));
+            // cross-attention keys / values of the new context positions, every denoiser layer
+            for (int l = 0; l < d.denoiser.num_layers; ++l) {
+                LCM_TRY(gemm(s, "ctx.cross_kv", s->act_a, dm, m->den[l].ca.k, nullptr, nullptr, s->cross_k + l * cross_layer, dm, R,
+                             LCMHIP_EPI_STORE, st, s->cross_rows, 0, nullptr, s->cap + 1));
+                LCM_TRY(gemm(s, "ctx.cross_kv", s->act_a, dm, m->den[l].ca.v, nullptr, nullptr, s->cross_v + l * cross_layer, dm, R,
+                             LCMHIP_EPI_STORE, st, s->cross_rows, 0, nullptr, s->cap + 1));
+            }
+            if (s->keep_context) {
+                if (d.dtype == LCMHIP_BF16)
+                    hipLaunchKernelGGL((k_keep_rows<bf16_t>), dim3(R), dim3(256), 0, st, (const bf16_t*)s->act_a, s->kept_ctx, s->self_rows, dm);
+                else
+                    hipLaunchKernelGGL((k_keep_rows<float>), dim3(R), dim3(256), 0, st, (const float*)s->act_a, s->kept_ctx, s->self_rows, dm);
+                LCM_HIP_CHECK(hipGetLastError());
+            }
+            // base LCM: postnet on the decoder output (projection.py:80-86), sampling noise, denormalize
+            if (bo && bo->out && (bo->all || j0 + sc == n_tokens)) {
+                LCM_TRY(gemm(s, "base.postnet", s->act_a, dm, m->postnet, nullptr, nullptr, s->f32tmp, D, R, LCMHIP_EPI_STORE_F32, st));
+                ProfScope ps(&s->prof, "base.out", R * (double)D * 8.0, 0.0, st);
+                float* g_out = bo->out + (size_t)d0 * n_out_pos * D;
+                const float* g_noise = bo->noise ? bo->noise + (size_t)d0 * n_out_pos * D : nullptr;
+                if (d.dtype == LCMHIP_BF16)
+                    hipLaunchKernelGGL((k_base_out<bf16_t>), dim3(R), dim3(128), 0, st, s->f32tmp, g_noise, (const bf16_t*)m->center,
+                                       (const bf16_t*)m->scale, g_out, D, sc, n_tokens, j0, bo->all, bo->temperature);
+                else
+                    hipLaunchKernelGGL((k_base_out<float>), dim3(R), dim3(128), 0, st, s->f32tmp, g_noise, (const float*)m->center,
+                                       (const float*)m->scale, g_out, D, sc, n_tokens, j0, bo->all, bo->temperature);
+                LCM_HIP_CHECK(hipGetLastError());
+            }
         }
-        LCM_TRY(norm(s, "ctx.norm", s->xres, m->ctx_final, nullptr, nullptr, s->act_a, R, R, tc.norm_kind, nullptr, st));
-        // cross-attention keys / values of the new context positions, every denoiser layer
-        for (int l = 0; l < d.denoiser.num_layers; ++l) {
-            LCM_TRY(gemm(s, "ctx.cross_kv", s->act_a, dm, m->den[l].ca.k, nullptr, nullptr, s->cross_k + l * cross_layer, dm, R,
-                         LCMHIP_EPI_STORE, st, s->cross_rows, 0, nullptr, s->cap + 1));
-            LCM_TRY(gemm(s, "ctx.cross_kv", s->act_a, dm, m->den[l].ca.v, nullptr, nullptr, s->cross_v + l * cross_layer, dm, R,
-                         LCMHIP_EPI_STORE, st, s->cross_rows, 0, nullptr, s->cap + 1));
-        }
-        if (s->keep_context) {
-            if (d.dtype == LCMHIP_BF16)
-                hipLaunchKernelGGL((k_keep_rows<bf16_t>), dim3(R), dim3(256), 0, st, (const bf16_t*)s->act_a, s->kept_ctx, s->self_rows, dm);
-            else
-                hipLaunchKernelGGL((k_keep_rows<float>), dim3(R), dim3(256), 0, st, (const float*)s->act_a, s->kept_ctx, s->self_rows, dm);
-            LCM_HIP_CHECK(hipGetLastError());
-        }
-        // base LCM: postnet on the decoder output (projection.py:80-86), sampling noise, denormalize
-        if (bo && bo->out && (bo->all || j0 + sc == n_tokens)) {
-            LCM_TRY(gemm(s, "base.postnet", s->act_a, dm, m->postnet, nullptr, nullptr, s->f32tmp, D, R, LCMHIP_EPI_STORE_F32, st));
-            ProfScope ps(&s->prof, "base.out", R * (double)D * 8.0, 0.0, st);
-            float* g_out = bo->out + (size_t)d0 * n_out_pos * D;
-            const float* g_noise = bo->noise ? bo->noise + (size_t)d0 * n_out_pos * D : nullptr;
-            if (d.dtype == LCMHIP_BF16)
-                hipLaunchKernelGGL((k_base_out<bf16_t>), dim3(R), dim3(128), 0, st, s->f32tmp, g_noise, (const bf16_t*)m->center,
-                                   (const bf16_t*)m->scale, g_out, D, sc, n_tokens, j0, bo->all, bo->temperature);
-            else
-                hipLaunchKernelGGL((k_base_out<float>), dim3(R), dim3(128), 0, st, s->f32tmp, g_noise, (const float*)m->center,
-                                   (const float*)m->scale, g_out, D, sc, n_tokens, j0, bo->all, bo->temperature);
-            LCM_HIP_CHECK(hipGetLastError());
-        }
-    }
     }
     s->ctx_len += n_tokens;
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), s->d_cross_keys, s->ctx_len + 1);
