@@ -156,3 +156,54 @@ class OracleGenerator:
                 pmask = pmask.index_select(0, active)
                 prompt_lens = prompt_lens.index_select(0, active)
         return hyps
+
+
+class OracleScorer(OracleGenerator):
+    """Teacher-forced scoring, lcm/inference/two_tower_diffusion_lcm/scorer.py:27-314: at every step the model sees
+    the gold previous sentence, the prediction is recorded (never fed back), and a document leaves the batch after
+    its last sentence."""
+
+    @torch.inference_mode()
+    def __call__(self, seqs_in: Tensor, text_lens: Optional[Tensor] = None, max_gen_len: Optional[int] = None,
+                 min_gen_len: Optional[int] = None, min_context_len: int = 1, noise: Optional[Tensor] = None,
+                 temperature: float = 0.0) -> List[List[Hyp]]:
+        opt, model = self.options, self.model
+        self.temperature = temperature if temperature != 0.0 else opt.lcm_temperature
+        B, T, D = seqs_in.shape
+        text_lens = torch.full((B,), T, dtype=torch.long) if text_lens is None else text_lens.clone()
+        max_gen_len = min(max_gen_len or opt.max_seq_len, T - min_context_len)       # scorer.py:84-94
+        assert max_gen_len <= opt.max_seq_len
+        min_gen_len = min_gen_len or opt.min_seq_len
+        assert min_gen_len > 0
+        cache = KVCache(T)
+        seqs = seqs_in.clone()
+        preds = torch.zeros(B, T - min_context_len, D)
+        step_scores = torch.zeros(B, T)
+        sample_idx = torch.arange(B)
+        hyps: List[List[Hyp]] = [[] for _ in range(B)]
+        prefill_len = min_context_len - 1                                             # scorer.py:163-199
+        if prefill_len > 0:
+            context = model.encode(model.normalize(seqs[:, :prefill_len]), cache)
+            cache.increment_step_nr(prefill_len)
+        else:
+            context = torch.empty(B, 0, model.model_dim)
+        for step_nr in range(min_context_len, T):
+            n_act = seqs.shape[0]
+            nz = (noise[step_nr - min_context_len].index_select(0, sample_idx).unsqueeze(1) if noise is not None
+                  else torch.randn(n_act, 1, D))
+            out, context = model.predict_next_sentence(seqs[:, step_nr - 1:step_nr], context, cache, nz)
+            # ---- finalize_step (scorer.py:243-280)
+            keep_going = text_lens.gt(step_nr + 1)
+            preds[:, step_nr - min_context_len] = out[:, -1]
+            for idx in (~keep_going).nonzero().flatten().tolist():
+                n = int(text_lens[idx])
+                hyps[int(sample_idx[idx])] = [Hyp(seq=preds[idx, :n - min_context_len].clone(), step_scores=step_scores[idx].clone())]
+            active = keep_going.nonzero().flatten()
+            if len(active) == 0:
+                break
+            cache.reorder(active)                                                     # scorer.py:292-314
+            context = context.index_select(0, active)
+            seqs, preds = seqs.index_select(0, active), preds.index_select(0, active)
+            sample_idx, step_scores = sample_idx.index_select(0, active), step_scores.index_select(0, active)
+            text_lens = text_lens.index_select(0, active)
+        return hyps

@@ -343,3 +343,27 @@ def test_random_stopping_patterns(seed):
     assert len(set(want)) > 1                                       # documents really finished at different steps
     worst, cos = compare(out.hypotheses, ref, sd)
     assert worst <= FP32_MAX_ABS and cos >= FP32_COS, (worst, cos)
+
+
+def test_teacher_forced_scorer():
+    """TwoTowerDiffusionLCMScorer against the oracle's restatement of the reference scorer: ragged documents,
+    min_context_len 1 and 3 (with and without a prefill)."""
+    from lcm.datasets.batch import EmbeddingsBatch, PaddingMask
+    from lcm.inference.two_tower_diffusion_lcm import DiffusionLCMGeneratorOptions, TwoTowerDiffusionLCMScorer
+    from lcm.models.two_tower_diffusion_lcm import create_two_tower_diffusion_lcm_model
+    from parity_utils import mini_config
+    arch = "mini_two_tower_diffusion_lcm"
+    lens = [6, 4, 5, 6]
+    cfg, sd, x, nz = make_problem(arch, 4, 6, 0, prompt_lens=lens)
+    opts = dict(DEFAULT_OPTS, inference_timesteps=5)
+    model = create_two_tower_diffusion_lcm_model(mini_config(), device="cuda:0", dtype=torch.float32)
+    model.load_state_dict(sd)
+    for mcl in (1, 3):
+        ref = oracle_mod.OracleScorer(oracle_mod.OracleTwoTower(cfg, sd), oracle_mod.GenOptions(**opts))(
+            x, text_lens=torch.tensor(lens), min_context_len=mcl, noise=nz)
+        scorer = TwoTowerDiffusionLCMScorer(model, DiffusionLCMGeneratorOptions(**opts))
+        out = scorer(EmbeddingsBatch(x.cuda(), PaddingMask(torch.tensor(lens, device="cuda:0"), 6)), min_context_len=mcl,
+                     noise=nz.cuda())
+        assert [h[0].seq.shape[0] for h in out.hypotheses] == [n - mcl for n in lens]
+        worst, cos = compare(out.hypotheses, ref, sd)
+        assert worst <= FP32_MAX_ABS and cos >= FP32_COS, (mcl, worst, cos)

@@ -265,3 +265,24 @@ def test_base_lcm_parameter_count():
     import math
     n = sum(math.prod(s) for name, s, kind in base_state_dict_spec(oracle.get_base_arch("base_lcm_1_6B")) if kind != "normalizer")
     assert n == 1_649_185_792      # the reconstructed 1.6B decoder; the reference's recipe comment states 1,647,635,456
+
+
+def test_scorer_prediction_equals_first_generated_sentence():
+    """Teacher forcing: the scorer's prediction for position t of a document is what the generator would produce as
+    its first sentence when prompted with the gold prefix [:t] and the same noise draw."""
+    cfg, m = _model("mini_two_tower_diffusion_lcm")
+    norm = oracle.load_dummy_normalizer()
+    lens = [5, 3, 4]
+    x = synthetic_prompts(norm, 3, 5)
+    for i, n in enumerate(lens):
+        x[i, n:] = 0
+    nz = synthetic_noise(4, 3)
+    opts = oracle.GenOptions(**OPTS, inference_timesteps=5)
+    for mcl in (1, 2):
+        scored = oracle.OracleScorer(m, opts)(x, text_lens=torch.tensor(lens), min_context_len=mcl, noise=nz)
+        gen = oracle.OracleGenerator(m, opts)
+        for i, n in enumerate(lens):
+            assert scored[i][0].seq.shape == (n - mcl, x.shape[-1])
+            for t in range(mcl, n):
+                first = gen(x[i:i + 1, :t], max_gen_len=1, noise=nz[t - mcl:t - mcl + 1, i:i + 1])[0][0].seq[-1]
+                assert torch.allclose(scored[i][0].seq[t - mcl], first, atol=1e-5), (mcl, i, t)
