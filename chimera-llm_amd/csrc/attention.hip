@@ -60,7 +60,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_attention(AttnQ qa, const T* __restrict__ kc, const T* __restrict__ vc,
                                                    const int32_t* __restrict__ slot_map, T* __restrict__ out, int s,
                                                    int n_heads, int cap, int base_keys, int causal,
-                                                   const int32_t* __restrict__ base_keys_dev) {
+                                                   const int32_t* __restrict__ base_keys_dev, KeyWindow win) {
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int heads_per_block = blockDim.x >> 6;
     const int hb = n_heads / heads_per_block;           // blocks per query row
@@ -69,7 +69,11 @@ __global__ __launch_bounds__(256) void k_attention(AttnQ qa, const T* __restrict
     const int doc = row / s, j = row % s;
     const int slot = slot_map ? slot_map[doc] : doc;
     // a launch recorded in a graph reads the key count from device memory: it changes with every appended position
-    const int nkeys = (base_keys_dev ? *base_keys_dev : base_keys) + (causal ? j + 1 : 0);
+    int nkeys = (base_keys_dev ? *base_keys_dev : base_keys) + (causal ? j + 1 : 0);
+    if (win.max_keys > 0) {   // per-document window (shifted causal mask + key padding)
+        if (win.shift) nkeys += win.shift[doc];
+        nkeys = max(1, min(nkeys, win.limit ? min(win.limit[doc], win.max_keys) : win.max_keys));
+    }
     const int d = n_heads * kHeadDim;
     const int ks = lane >> 2, dg = lane & 3;
     const int col = head * kHeadDim + dg * 8;           // piece i of this lane starts at col + 32 * i
@@ -247,7 +251,8 @@ constexpr int kPfVRow = 64 + 16;                   // padded V^T row: 32 key slo
 
 __global__ __launch_bounds__(256) void k_attention_prefill(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
                                                            const bf16_t* __restrict__ vc, const int32_t* __restrict__ slot_map,
-                                                           bf16_t* __restrict__ out, int s, int n_heads, int cap, int base_keys) {
+                                                           bf16_t* __restrict__ out, int s, int n_heads, int cap, int base_keys,
+                                                           KeyWindow win) {
     __shared__ __attribute__((aligned(16))) char smem[kPfKeys * kPfKRow + kHeadDim * kPfVRow];
     char* ks = smem;
     char* vs = smem + kPfKeys * kPfKRow;
@@ -261,9 +266,16 @@ __global__ __launch_bounds__(256) void k_attention_prefill(const bf16_t* __restr
     const int qi = lane & 15, quad = lane >> 4;
     const int j = qt * 64 + wid * 16 + qi;             // query index inside the document's block of s
     const int jc = j < s ? j : s - 1;                   // rows past the end repeat the last query; never stored
-    const int my_keys = base_keys + jc + 1;             // keys this query sees
-    const int block_keys = base_keys + min(s, qt * 64 + 64);   // keys the last query of the workgroup sees
-    const int wave_keys = base_keys + min(s, qt * 64 + wid * 16 + 16);
+    int my_keys = base_keys + jc + 1;                   // keys this query sees
+    int block_keys = base_keys + min(s, qt * 64 + 64);  // keys the last query of the workgroup sees
+    int wave_keys = base_keys + min(s, qt * 64 + wid * 16 + 16);
+    if (win.max_keys > 0) {   // per-document window (shifted causal mask + key padding); uniform per workgroup
+        const int sh = win.shift ? win.shift[doc] : 0;
+        const int lim = win.limit ? min(win.limit[doc], win.max_keys) : win.max_keys;
+        my_keys = max(1, min(my_keys + sh, lim));
+        block_keys = max(1, min(block_keys + sh, lim));
+        wave_keys = max(1, min(wave_keys + sh, lim));
+    }
 
     // Q^T fragments: dims 32 * st + 8 * quad .. + 7 of query qi, pre-scaled by 1 / sqrt(128) in fp32 like the reference
     bf16x8_t qf[4];
@@ -369,10 +381,14 @@ __global__ __launch_bounds__(256) void k_attention_prefill(const bf16_t* __restr
 
 int launch_attention_q(const AttnQ& qa, const void* kc, const void* vc, const int32_t* slot_map, void* out, int n_docs,
                        int s, int n_heads, int cap, int base_keys, int causal, int dtype, hipStream_t st,
-                       const int32_t* base_keys_dev) {
+                       const int32_t* base_keys_dev, const KeyWindow* win) {
     LCM_REQUIRE(n_heads % 4 == 0 || n_heads == 2, "attention: heads must be a multiple of 4 (or 2)");
     LCM_REQUIRE(n_docs >= 0 && s >= 1 && base_keys >= 0, "attention: bad shape");
-    const int max_keys = base_keys + (causal ? s : 0);
+    KeyWindow kw;
+    if (win) kw = *win;
+    LCM_REQUIRE(kw.max_keys >= 0 && kw.max_keys <= cap, "attention: key window exceeds the cache");
+    LCM_REQUIRE(kw.max_keys > 0 || (kw.shift == nullptr && kw.limit == nullptr), "attention: a key window needs max_keys");
+    const int max_keys = kw.max_keys > 0 ? kw.max_keys : base_keys + (causal ? s : 0);
     LCM_REQUIRE(max_keys >= 1 && max_keys <= cap, "attention: key range exceeds the cache");
     LCM_REQUIRE((qa.q != nullptr) != (qa.partial != nullptr), "attention: exactly one query source");
     if (n_docs == 0) return LCMHIP_OK;
@@ -381,7 +397,7 @@ int launch_attention_q(const AttnQ& qa, const void* kc, const void* vc, const in
         const int qtiles = (s + 63) / 64;
         hipLaunchKernelGGL(k_attention_prefill, dim3((unsigned)(n_docs * n_heads * qtiles)), dim3(256), 0, st,
                            (const bf16_t*)qa.q, (const bf16_t*)kc, (const bf16_t*)vc, slot_map, (bf16_t*)out, s, n_heads, cap,
-                           base_keys);
+                           base_keys, kw);
         LCM_HIP_CHECK(hipGetLastError());
         return LCMHIP_OK;
     }
@@ -389,10 +405,10 @@ int launch_attention_q(const AttnQ& qa, const void* kc, const void* vc, const in
     dim3 grid((unsigned)(n_docs * s * (n_heads / waves))), block(64 * waves);
     if (dtype == LCMHIP_BF16)
         hipLaunchKernelGGL((k_attention<bf16_t>), grid, block, 0, st, qa, (const bf16_t*)kc, (const bf16_t*)vc, slot_map,
-                           (bf16_t*)out, s, n_heads, cap, base_keys, causal, base_keys_dev);
+                           (bf16_t*)out, s, n_heads, cap, base_keys, causal, base_keys_dev, kw);
     else if (dtype == LCMHIP_F32)
         hipLaunchKernelGGL((k_attention<float>), grid, block, 0, st, qa, (const float*)kc, (const float*)vc, slot_map,
-                           (float*)out, s, n_heads, cap, base_keys, causal, base_keys_dev);
+                           (float*)out, s, n_heads, cap, base_keys, causal, base_keys_dev, kw);
     else
         return fail(LCMHIP_ERR_INVALID, "attention: unknown dtype");
     LCM_HIP_CHECK(hipGetLastError());
@@ -403,7 +419,7 @@ int launch_attention(const void* q, const void* kc, const void* vc, const int32_
                      int s, int n_heads, int cap, int base_keys, int causal, int dtype, hipStream_t st) {
     AttnQ qa{};
     qa.q = q;
-    return launch_attention_q(qa, kc, vc, slot_map, out, n_docs, s, n_heads, cap, base_keys, causal, dtype, st, nullptr);
+    return launch_attention_q(qa, kc, vc, slot_map, out, n_docs, s, n_heads, cap, base_keys, causal, dtype, st, nullptr, nullptr);
 }
 
 }  // namespace lcmhip

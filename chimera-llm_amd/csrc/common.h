@@ -173,6 +173,23 @@ struct Pending {
     int init = 0;
 };
 
+// Per-row modulation: row r takes shift / scale (and a pending product's gate) at offset row_step[r] * step_stride
+// floats from the pointers given (one modulation table entry per diffusion step); indices are clamped to
+// [0, n_steps).  row_step == nullptr: every row reads the pointers as they are.
+struct RowSteps {
+    const int32_t* row_step = nullptr;
+    size_t step_stride = 0;
+    int n_steps = 1;
+};
+
+// Per-document key window of a causal attention launch: query j of document i sees
+//   clamp(base_keys + shift[i] + j + 1, 1, min(limit[i], max_keys)) keys.  Null arrays mean 0 / max_keys.
+struct KeyWindow {
+    const int32_t* shift = nullptr;
+    const int32_t* limit = nullptr;
+    int max_keys = 0;
+};
+
 int launch_normalize(const void* x, const void* center, const void* scale, const void* cmin, const void* cmax,
                      void* y, int64_t rows, int dim, int dtype, bool inverse, hipStream_t st);
 // fp32 in -> T out, used by the frontend: y = (x - center) / scale with T-typed center/scale.
@@ -182,7 +199,7 @@ int launch_normalize_f32_in(const float* x, const void* center, const void* scal
 // of x first absorb the pending product (x is updated in place).
 int launch_norm_modulate(float* x, const void* w, const void* b, const float* shift, const float* scale,
                          void* y, int rows_total, int rows_norm, int dim, int norm_kind, float eps, int dtype,
-                         const Pending* pend, hipStream_t st);
+                         const Pending* pend, hipStream_t st, const RowSteps* steps = nullptr);
 int launch_attention(const void* q, const void* kc, const void* vc, const int32_t* slot_map, void* out, int n_docs,
                      int s, int n_heads, int cap, int base_keys, int causal, int dtype, hipStream_t st);
 // Query source of the attention kernel: a finished (rows, d) tensor, or the split-K slab of the q projection.
@@ -195,7 +212,7 @@ struct AttnQ {
 };
 int launch_attention_q(const AttnQ& qa, const void* kc, const void* vc, const int32_t* slot_map, void* out, int n_docs,
                        int s, int n_heads, int cap, int base_keys, int causal, int dtype, hipStream_t st,
-                       const int32_t* base_keys_dev = nullptr);
+                       const int32_t* base_keys_dev = nullptr, const KeyWindow* win = nullptr);
 
 struct DdimScalars {
     float sqrt_a_t, sqrt_b_t;        // sqrt(alpha_prod_t), sqrt(1 - alpha_prod_t)

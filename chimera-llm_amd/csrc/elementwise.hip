@@ -145,10 +145,15 @@ template <typename T, int KIND, int NT>
 __global__ __launch_bounds__(NT) void k_norm_modulate(float* __restrict__ x, const T* __restrict__ w,
                                                        const T* __restrict__ b, const float* __restrict__ shift,
                                                        const float* __restrict__ scale, T* __restrict__ y, int dim,
-                                                       int rows_norm, float eps, Pending pd) {
+                                                       int rows_norm, float eps, Pending pd, RowSteps rs) {
     constexpr int MAXV = 2048 / NT;  // float4 chunks per lane (dim <= 8192)
     __shared__ float red[NT / 64];
     const int row = blockIdx.x;
+    if (rs.row_step != nullptr) {   // this row's own entry of the modulation table
+        const size_t moff = (size_t)min(max(rs.row_step[row], 0), rs.n_steps - 1) * rs.step_stride;
+        if (shift != nullptr) { shift += moff; scale += moff; }
+        if (pd.gate != nullptr) pd.gate += moff;
+    }
     float* xr = x + (size_t)row * dim;
     const int nv = dim / 4;
     float4 v[MAXV];
@@ -346,7 +351,7 @@ static bool launch_norm_rows(const float* x, const void* w, const void* b, const
 
 int launch_norm_modulate(float* x, const void* w, const void* b, const float* shift, const float* scale,
                          void* y, int rows_total, int rows_norm, int dim, int norm_kind, float eps, int dtype,
-                         const Pending* pend, hipStream_t st) {
+                         const Pending* pend, hipStream_t st, const RowSteps* steps) {
     LCM_REQUIRE(dim % 4 == 0 && dim <= 8192, "norm: dim must be a multiple of 4 and <= 8192");
     LCM_REQUIRE((shift == nullptr) == (scale == nullptr), "norm: shift and scale go together");
     LCM_REQUIRE(w != nullptr, "norm: weight required");
@@ -361,7 +366,12 @@ int launch_norm_modulate(float* x, const void* w, const void* b, const float* sh
     }
     const int rows = pend ? rows_total : rows_norm;
     if (rows <= 0) return LCMHIP_OK;
-    if (!pend && rows >= 1024) {
+    RowSteps rs;
+    if (steps) {
+        rs = *steps;
+        LCM_REQUIRE(rs.row_step == nullptr || rs.n_steps >= 1, "norm: per-row steps need a table size");
+    }
+    if (!pend && rows >= 1024 && rs.row_step == nullptr) {
         bool done = false;
         if (dtype == LCMHIP_BF16)
             done = norm_kind == LCMHIP_NORM_RMS ? launch_norm_rows<bf16_t, LCMHIP_NORM_RMS>(x, w, b, shift, scale, y, rows, dim, eps, st)
@@ -378,10 +388,10 @@ int launch_norm_modulate(float* x, const void* w, const void* b, const float* sh
 #define LCM_NORM(T, KIND)                                                                                      \
     if (dim >= 2048)                                                                                           \
         hipLaunchKernelGGL((k_norm_modulate<T, KIND, 512>), dim3(rows), dim3(512), 0, st, x, (const T*)w,      \
-                           (const T*)b, shift, scale, (T*)y, dim, rows_norm, eps, pd);                         \
+                           (const T*)b, shift, scale, (T*)y, dim, rows_norm, eps, pd, rs);                     \
     else                                                                                                       \
         hipLaunchKernelGGL((k_norm_modulate<T, KIND, 256>), dim3(rows), dim3(256), 0, st, x, (const T*)w,      \
-                           (const T*)b, shift, scale, (T*)y, dim, rows_norm, eps, pd)
+                           (const T*)b, shift, scale, (T*)y, dim, rows_norm, eps, pd, rs)
     if (dtype == LCMHIP_BF16) {
         if (norm_kind == LCMHIP_NORM_RMS) { LCM_NORM(bf16_t, LCMHIP_NORM_RMS); } else { LCM_NORM(bf16_t, LCMHIP_NORM_LAYERNORM); }
     } else if (dtype == LCMHIP_F32) {

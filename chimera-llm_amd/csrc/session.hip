@@ -296,6 +296,19 @@ __global__ void k_make_rows(const int32_t* __restrict__ slot_map, int32_t* pos, 
 
 __global__ void k_set_int(int32_t* p, int32_t v) { *p = v; }
 
+__global__ void k_add_int(const int32_t* __restrict__ src, int32_t* __restrict__ dst, int n, int add) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i] + add;
+}
+
+// Row r = (doc i = r / sc, position j0 + r % sc) of a pass over (n, n_pos) items: dst[r] = src[i * n_pos + j0 + r % sc]
+__global__ void k_gather_rows_int(const int32_t* __restrict__ src, int32_t* __restrict__ dst, int rows, int sc, int n_pos,
+                                  int j0) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    dst[r] = src[(size_t)(r / sc) * n_pos + j0 + r % sc];
+}
+
 __global__ void k_slot0_rows(int32_t* slot0_rows, int32_t* slot_map, int n, int cap1) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -439,14 +452,14 @@ static int gemm_pending(lcmhip_session* s, const char* tag, const void* A, int l
 
 static int norm(lcmhip_session* s, const char* tag, float* x, const NormW& w, const float* shift,
                 const float* scale, void* y, int rows_total, int rows_norm, int kind, const Pending* pend,
-                hipStream_t st) {
+                hipStream_t st, const RowSteps* steps = nullptr) {
     const lcmhip_model_desc& d = s->model->desc;
     const double es = (double)dtype_size(d.dtype);
     double bytes = rows_norm * (double)d.model_dim * (4.0 + es);
     if (pend) bytes += (double)rows_total * d.model_dim * 4.0 * (1.0 + pend->splits);
     ProfScope ps(&s->prof, tag, bytes, 0.0, st);
     return launch_norm_modulate(x, w.w, w.b, shift, scale, y, rows_total, rows_norm, d.model_dim, kind, d.norm_eps,
-                                d.dtype, pend, st);
+                                d.dtype, pend, st, steps);
 }
 
 static int ffn_in(lcmhip_session* s, const char* tag, const lcmhip_tower_desc& t, const FfnW& f, const void* a, int rows,
@@ -990,6 +1003,108 @@ int lcmhip_denoise(lcmhip_session* s, const float* noise, float* out, float* lat
     LCM_HIP_CHECK(hipMemcpyAsync(s->noise_buf, noise, io_bytes, hipMemcpyDeviceToDevice, st));
     LCM_HIP_CHECK(hipGraphLaunch(it->second, st));
     LCM_HIP_CHECK(hipMemcpyAsync(out, s->out_buf, io_bytes, hipMemcpyDeviceToDevice, st));
+    return LCMHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ all positions at once
+// The denoiser over every position of every document in one pass (the training / validation shape of the model):
+// position j of document i has its own noisy latent and its own diffusion step, its self-attention sees only
+// itself (diagonal mask, so the block is output_proj(v_proj(h)) as in the sampling loop), and its cross-attention
+// sees the zero slot plus context positions [0, j + shift_i) (lower-triangular mask moved by the source length),
+// cut at the document's context length.  Rows are independent given the cross K/V cache, so the pass is cut into
+// document groups (and long documents into position ranges) of at most chunk_rows rows.
+int lcmhip_denoise_positions(lcmhip_session* s, const float* noisy, const int32_t* step_index, int32_t n_positions,
+                             const int32_t* source_lengths, const int32_t* context_lengths, float* out, void* stream) {
+    LCM_REQUIRE(s && noisy && step_index && out, "denoise_positions: null argument");
+    LCM_REQUIRE(!s->model->base, "denoise_positions: a base LCM has no denoiser");
+    if (!s->have_schedule) return fail(LCMHIP_ERR_STATE, "denoise_positions: call session_set_schedule first (it builds the modulation table)");
+    LCM_REQUIRE(s->n_active >= 1, "denoise_positions: call session_reset first");
+    LCM_REQUIRE(n_positions >= 1 && n_positions <= 65536, "denoise_positions: bad position count");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    lcmhip_model* m = s->model;
+    const lcmhip_model_desc& d = m->desc;
+    const lcmhip_tower_desc& td = d.denoiser;
+    const int dm = d.model_dim, D = d.sonar_dim, L = td.num_layers;
+    const size_t es = dtype_size(d.dtype);
+    const size_t cross_layer = (size_t)s->max_batch * (s->cap + 1) * dm * es;
+    RowSteps rs;
+    rs.row_step = s->pos_rows;
+    rs.step_stride = (size_t)L * 9 * dm;
+    rs.n_steps = s->n_steps;
+    KeyWindow win;
+    win.shift = nullptr;
+    win.limit = nullptr;
+    win.max_keys = s->ctx_len + 1;   // zero slot + the positions appended so far
+
+    const int n_total = s->n_active;
+    const int doc_group = std::max(1, std::min(n_total, s->chunk_rows / std::min(n_positions, s->chunk_rows)));
+    for (int d0 = 0; d0 < n_total; d0 += doc_group) {
+        const int n = std::min(doc_group, n_total - d0);
+        const int per_chunk = std::max(1, s->chunk_rows / n);
+        const float* xg = noisy + (size_t)d0 * n_positions * D;
+        const int32_t* slots = s->slot_map + d0;
+        win.shift = source_lengths ? source_lengths + d0 : nullptr;
+        if (context_lengths) {
+            // key limit = context length + 1 (the zero slot); built per pass in cross_rows
+            win.limit = s->cross_rows;
+        }
+        for (int j0 = 0; j0 < n_positions; j0 += per_chunk) {
+            const int sc = std::min(per_chunk, n_positions - j0);
+            const int R = n * sc;
+            hipLaunchKernelGGL(k_gather_rows_int, dim3((R + 255) / 256), dim3(256), 0, st, step_index + (size_t)d0 * n_positions,
+                               s->pos_rows, R, sc, n_positions, j0);
+            if (context_lengths)
+                hipLaunchKernelGGL(k_add_int, dim3((n + 255) / 256), dim3(256), 0, st, context_lengths + d0, s->cross_rows, n, 1);
+            LCM_HIP_CHECK(hipGetLastError());
+            // latents of this pass, operand dtype (no normalizer: the caller's latents live in normalized space)
+            if (d.dtype == LCMHIP_BF16)
+                hipLaunchKernelGGL((k_normalize_gather<bf16_t>), dim3(R), dim3(128), 0, st, xg, (const bf16_t*)nullptr,
+                                   (const bf16_t*)nullptr, (bf16_t*)s->act_in, D, sc, n_positions, j0, 0, 1.0f);
+            else
+                hipLaunchKernelGGL((k_normalize_gather<float>), dim3(R), dim3(128), 0, st, xg, (const float*)nullptr,
+                                   (const float*)nullptr, (float*)s->act_in, D, sc, n_positions, j0, 0, 1.0f);
+            LCM_HIP_CHECK(hipGetLastError());
+            Pending pend;
+            LCM_TRY(gemm_pending(s, "pos.initial_proj", s->act_in, D, m->init_proj, nullptr, R, &pend, st));
+            pend.init = 1;
+            for (int l = 0; l < L; ++l) {
+                const DenLayer& Ly = m->den[l];
+                const float* mod = s->mod_table + (size_t)l * 9 * dm;   // step 0; rows add their own step offset
+                LCM_TRY(norm(s, "pos.norm_mod", s->xres, Ly.sa_norm, mod, mod + dm, s->act_a, R, R, td.norm_kind, &pend, st, &rs));
+                if (Ly.ov.w != nullptr) {
+                    LCM_TRY(gemm_pending(s, "pos.self_ov", s->act_a, dm, Ly.ov, mod + 2 * dm, R, &pend, st));
+                } else {
+                    LCM_TRY(gemm(s, "pos.self_v", s->act_a, dm, Ly.sa.v, nullptr, nullptr, s->act_v, dm, R, LCMHIP_EPI_STORE, st));
+                    LCM_TRY(gemm_pending(s, "pos.self_o", s->act_v, dm, Ly.sa.o, mod + 2 * dm, R, &pend, st));
+                }
+                LCM_TRY(norm(s, "pos.norm_mod", s->xres, Ly.ca_norm, mod + 3 * dm, mod + 4 * dm, s->act_a, R, R, td.norm_kind, &pend, st, &rs));
+                LCM_TRY(gemm(s, "pos.cross_q", s->act_a, dm, Ly.ca.q, nullptr, nullptr, s->act_q, dm, R, LCMHIP_EPI_STORE, st));
+                {
+                    AttnQ qa{};
+                    qa.q = s->act_q;
+                    ProfScope ps(&s->prof, "pos.cross_attn", 2.0 * n * (double)win.max_keys * dm * es + 2.0 * R * dm * es,
+                                 2.0 * R * (double)std::min(win.max_keys, j0 + sc + 1) * dm, st);
+                    LCM_TRY(launch_attention_q(qa, s->cross_k + l * cross_layer, s->cross_v + l * cross_layer, slots, s->act_o, n, sc,
+                                               td.num_heads, s->cap + 1, j0, 1, d.dtype, st, nullptr, &win));
+                }
+                LCM_TRY(gemm_pending(s, "pos.cross_o", s->act_o, dm, Ly.ca.o, mod + 5 * dm, R, &pend, st));
+                LCM_TRY(norm(s, "pos.norm_mod", s->xres, Ly.ffn_norm, mod + 6 * dm, mod + 7 * dm, s->act_a, R, R, td.norm_kind, &pend, st, &rs));
+                LCM_TRY(ffn_in(s, "pos.ffn_in", td, Ly.ffn, s->act_a, R, st));
+                LCM_TRY(gemm_pending(s, "pos.ffn_out", s->act_h, td.ffn_dim, Ly.ffn.out, mod + 8 * dm, R, &pend, st));
+            }
+            // final norm: no modulation, but the last gate is still the row's own
+            LCM_TRY(norm(s, "pos.norm_mod", s->xres, m->den_final, nullptr, nullptr, s->act_a, R, R, td.norm_kind, &pend, st, &rs));
+            LCM_TRY(gemm(s, "pos.final_proj", s->act_a, dm, m->final_proj, nullptr, nullptr, s->f32tmp, D, R, LCMHIP_EPI_STORE_F32, st));
+            float* g_out = out + (size_t)d0 * n_positions * D;
+            if (d.dtype == LCMHIP_BF16)
+                hipLaunchKernelGGL((k_base_out<bf16_t>), dim3(R), dim3(128), 0, st, s->f32tmp, (const float*)nullptr,
+                                   (const bf16_t*)nullptr, (const bf16_t*)nullptr, g_out, D, sc, n_positions, j0, 1, 0.f);
+            else
+                hipLaunchKernelGGL((k_base_out<float>), dim3(R), dim3(128), 0, st, s->f32tmp, (const float*)nullptr,
+                                   (const float*)nullptr, (const float*)nullptr, g_out, D, sc, n_positions, j0, 1, 0.f);
+            LCM_HIP_CHECK(hipGetLastError());
+        }
+    }
     return LCMHIP_OK;
 }
 

@@ -26,6 +26,7 @@ EXPORTS = [
     "lcmhip_model_create", "lcmhip_model_bind_weight", "lcmhip_model_finalize", "lcmhip_model_destroy",
     "lcmhip_session_workspace_bytes", "lcmhip_session_create", "lcmhip_session_destroy",
     "lcmhip_session_set_schedule", "lcmhip_session_reset", "lcmhip_context_append", "lcmhip_base_forward", "lcmhip_denoise",
+    "lcmhip_denoise_positions",
     "lcmhip_session_reorder", "lcmhip_session_context_len", "lcmhip_session_num_active",
     "lcmhip_session_read_context", "lcmhip_session_profile_enable", "lcmhip_session_profile",
     "lcmhip_normalize", "lcmhip_denormalize", "lcmhip_norm_modulate", "lcmhip_gemm", "lcmhip_gemm_partial",
@@ -81,6 +82,7 @@ def _load() -> C.CDLL:
         "lcmhip_context_append": [vp, vp, i32, i32, vp],
         "lcmhip_base_forward": [vp, vp, i32, i32, vp, f32, i32, vp, vp],
         "lcmhip_denoise": [vp, vp, vp, vp, vp],
+        "lcmhip_denoise_positions": [vp, vp, vp, i32, vp, vp, vp, vp],
         "lcmhip_session_reorder": [vp, C.POINTER(i32), i32, vp],
         "lcmhip_session_context_len": [vp],
         "lcmhip_session_num_active": [vp],

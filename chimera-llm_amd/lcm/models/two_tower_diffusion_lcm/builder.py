@@ -158,26 +158,36 @@ class DeviceSession:
     def _stream(self):
         return _hip.stream_ptr(self.model.device)
 
-    def set_schedule(self) -> None:
+    def set_schedule(self, timesteps: Optional[List[int]] = None) -> None:
+        """Sampling schedule of the model's scheduler, or (with `timesteps`) only the adaLN table of the given
+        diffusion timesteps for `denoise_positions` (no guidance, sampling scalars unused)."""
         m = self.model
         sch = m.noise_scheduler
-        key = m._schedule_key()
+        if timesteps is None:
+            key = m._schedule_key()
+            ts = [int(t) for t in sch.timesteps.tolist()]
+            params = _hip.DenoiseParams(
+                guidance_scale=float(m.guidance_scale), guidance_rescale=float(m.guidance_rescale),
+                ddim_eta=float(m.ddim_eta), epsilon_scaling=float(m.epsilon_scaling) if m.epsilon_scaling else 0.0,
+                clip_noise=float(m.clip_noise), init_noise_sigma=float(sch.init_noise_sigma),
+                prediction_type=_hip.PRED[sch.prediction_type], clip_sample=int(sch.config.clip_sample),
+                clip_sample_range=float(sch.config.clip_sample_range))
+        else:
+            ts = [int(t) for t in timesteps]
+            key = ("table", tuple(ts))
+            params = _hip.DenoiseParams(
+                guidance_scale=1.0, guidance_rescale=0.0, ddim_eta=0.0, epsilon_scaling=0.0, clip_noise=100.0,
+                init_noise_sigma=1.0, prediction_type=_hip.PRED[sch.prediction_type], clip_sample=0, clip_sample_range=1.0)
         if key == self.schedule_key:
             return
-        ts = [int(t) for t in sch.timesteps.tolist()]
+        step_ratio = sch.step_ratio if timesteps is None else 1
         ts_arr = (C.c_int32 * len(ts))(*ts)
         ac = sch.alphas_cumprod.tolist()
         ac_arr = (C.c_float * len(ac))(*ac)
-        params = _hip.DenoiseParams(
-            guidance_scale=float(m.guidance_scale), guidance_rescale=float(m.guidance_rescale),
-            ddim_eta=float(m.ddim_eta), epsilon_scaling=float(m.epsilon_scaling) if m.epsilon_scaling else 0.0,
-            clip_noise=float(m.clip_noise), init_noise_sigma=float(sch.init_noise_sigma),
-            prediction_type=_hip.PRED[sch.prediction_type], clip_sample=int(sch.config.clip_sample),
-            clip_sample_range=float(sch.config.clip_sample_range))
         if sch.config.thresholding:
             raise NotImplementedError("dynamic thresholding is not implemented on the HIP path")
         _hip.check(_hip.lib.lcmhip_session_set_schedule(
-            self._h, ts_arr, len(ts), ac_arr, len(ac), float(sch.final_alpha_cumprod), sch.step_ratio,
+            self._h, ts_arr, len(ts), ac_arr, len(ac), float(sch.final_alpha_cumprod), step_ratio,
             C.byref(params), self._stream()))
         self.schedule_key = key
 
@@ -217,6 +227,29 @@ class DeviceSession:
         assert nz.shape[0] == self.num_active
         out = torch.empty_like(nz)
         _hip.check(_hip.lib.lcmhip_denoise(self._h, _hip.ptr(nz), _hip.ptr(out), _hip.ptr(trace), self._stream()))
+        return out
+
+    def denoise_positions(self, noisy: Tensor, step_index: Tensor, source_lengths: Optional[Tensor] = None,
+                          context_lengths: Optional[Tensor] = None) -> Tensor:
+        """noisy (n_active, T, D) latents in normalized space, step_index (n_active, T) indices into the table set by
+        `set_schedule(timesteps)`; optional per-document source / context lengths -> model output (n_active, T, D) fp32."""
+        _hip.require_gpu(noisy, "noisy latents")
+        x32 = noisy.float().contiguous()
+        assert x32.dim() == 3 and x32.shape[0] == self.num_active, (tuple(x32.shape), self.num_active)
+        idx = step_index.to(device=x32.device, dtype=torch.int32).contiguous()
+        assert tuple(idx.shape) == tuple(x32.shape[:2]), (tuple(idx.shape), tuple(x32.shape))
+
+        def per_doc(t: Optional[Tensor]) -> Optional[Tensor]:
+            if t is None:
+                return None
+            t = t.to(device=x32.device, dtype=torch.int32).contiguous()
+            assert tuple(t.shape) == (x32.shape[0],), tuple(t.shape)
+            return t
+
+        src, ctx = per_doc(source_lengths), per_doc(context_lengths)
+        out = torch.empty_like(x32)
+        _hip.check(_hip.lib.lcmhip_denoise_positions(self._h, _hip.ptr(x32), _hip.ptr(idx), x32.shape[1], _hip.ptr(src),
+                                                     _hip.ptr(ctx), _hip.ptr(out), self._stream()))
         return out
 
     def reorder(self, order) -> None:
@@ -416,10 +449,13 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
         return (tuple(s.timesteps.tolist()), self.guidance_scale, self.guidance_rescale, self.ddim_eta,
                 self.epsilon_scaling, self.clip_noise, s.init_noise_sigma, s.prediction_type)
 
-    def acquire_session(self, max_batch: int, max_ctx: int) -> DeviceSession:
-        assert hasattr(self, "clip_noise"), (
-            "The model is not properly set for decoding, make sure to call `model.prep_for_denoising()`")
-        steps = len(self.noise_scheduler.timesteps)
+    def acquire_session(self, max_batch: int, max_ctx: int, timesteps: Optional[List[int]] = None) -> DeviceSession:
+        if timesteps is None:
+            assert hasattr(self, "clip_noise"), (
+                "The model is not properly set for decoding, make sure to call `model.prep_for_denoising()`")
+            steps = len(self.noise_scheduler.timesteps)
+        else:
+            steps = len(timesteps)
         for i, s in enumerate(self._session_pool):
             if s.dims[0] >= max_batch and s.dims[1] >= max_ctx and s.dims[2] >= steps:
                 sess = self._session_pool.pop(i)
@@ -427,7 +463,7 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
         else:
             self._session_pool.clear()   # one workspace at a time: they are large
             sess = DeviceSession(self, max_batch, max_ctx, steps)
-        sess.set_schedule()
+        sess.set_schedule(timesteps)
         return sess
 
     def release_session(self, sess: Optional[DeviceSession]) -> None:
@@ -447,6 +483,29 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
         assert hasattr(self, "clip_noise"), (
             "The model is not properly set for decoding, make sure to call `model.prep_for_denoising()`")
         return torch.randn(batch_size, 1, self.config.sonar_embed_dim, device=self.device)
+
+    @torch.inference_mode()
+    def forward(self, batch: EmbeddingsBatch, noisy_batch: EmbeddingsBatch, cf_guidance_prob: float = 0.0) -> EmbeddingsBatch:
+        """The reference's training-shaped forward (builder.py:128-159) in inference mode: contextualize the clean
+        `batch` (normalized embeddings, optional padding mask, optional `source_lengths`), then denoise every position
+        of `noisy_batch` (latents + per-position `diffusion_timesteps`) against the causally shifted context.
+        Returns the model output (B, T, D) fp32 with the noisy batch's padding mask."""
+        if cf_guidance_prob != 0.0:
+            raise NotImplementedError("cf_guidance_prob > 0 drops random conditioning rows (training only); not implemented on the HIP path")
+        x, noisy, ts = batch.seqs, noisy_batch.seqs, noisy_batch.diffusion_timesteps
+        assert ts is not None, "noisy_batch.diffusion_timesteps is required"
+        assert x.shape[0] == noisy.shape[0]
+        ts = ts.reshape(noisy.shape[0], noisy.shape[1])
+        uniq, inverse = torch.unique(ts, sorted=True, return_inverse=True)
+        sess = self.acquire_session(x.shape[0], x.shape[1], timesteps=uniq.tolist())
+        try:
+            sess.reset(x.shape[0])
+            sess.append(x, normalized=True)
+            ctx_lens = batch.padding_mask.seq_lens if batch.padding_mask is not None else None
+            out = sess.denoise_positions(noisy, inverse, batch.source_lengths, ctx_lens)
+        finally:
+            self.release_session(sess)
+        return EmbeddingsBatch(out, noisy_batch.padding_mask)
 
     @torch.inference_mode()
     def encode(self, batch: EmbeddingsBatch, state_bag: Optional[LCMIncrementalStateBag] = None,

@@ -181,6 +181,22 @@ int lcmhip_base_forward(lcmhip_session* s, const float* x, int32_t n_tokens, int
 int lcmhip_denoise(lcmhip_session* s, const float* noise, float* out, float* latents_trace,
                    void* stream);
 
+/* The denoiser over every position of every active document in one pass: the denoising half of
+ * TwoTowerDiffusionLCModel.forward (builder.py:128-159, 193-213) = LCMDenoiser.forward with inference=False
+ * (lcm_denoiser.py:152-251): diagonal self-attention mask (attention_masks.py:82-113) and the
+ * ShiftedCausalAttentionMask over [zero vector, context] (attention_masks.py:158-228, cf_guidance_prob = 0).
+ * The context half is lcmhip_context_append on a freshly reset session (the whole clean batch at once).
+ * `noisy` (n_active, n_positions, sonar_dim) fp32: noised latents in normalized space;
+ * `step_index` (n_active, n_positions) int32 DEVICE array: for every position the index of its diffusion timestep
+ * in the timestep list last given to lcmhip_session_set_schedule (whose adaLN table is reused; out-of-range
+ * indices are clamped); `source_lengths` (n_active) int32 device array or NULL (= 0): position j sees the zero
+ * vector and context positions [0, j + source_length); `context_lengths` (n_active) int32 device array or NULL:
+ * valid context positions per document (key padding mask; NULL = all appended positions).
+ * `out` (n_active, n_positions, sonar_dim) fp32 receives the model output (normalized space, no scheduler step). */
+int lcmhip_denoise_positions(lcmhip_session* s, const float* noisy, const int32_t* step_index,
+                             int32_t n_positions, const int32_t* source_lengths,
+                             const int32_t* context_lengths, float* out, void* stream);
+
 /* Replaces TwoTowerDiffusionLCMGenerator.reorder_state (generator.py:442-466) for the caches:
  * afterwards active row i is the row that was `order[i]` (HOST array, strictly increasing). No
  * cache bytes move. */

@@ -201,10 +201,11 @@ class OracleTwoTower:
 
     # -- denoiser (lcm_denoiser.py:152-251, 388-546)
     def denoise(self, latents: Tensor, timesteps: Tensor, context: Tensor,
-                ctx_lens: Optional[Tensor] = None) -> Tensor:
-        """latents (N,1,D), timesteps (N,1) long, context (N,t,d); ctx_lens (N,) visible context
-        length per row or None.  Inference path: diagonal self mask, no cross mask, key padding
-        from ctx_lens shifted by the prepended zero vector."""
+                ctx_lens: Optional[Tensor] = None, cross_mask: Optional[Tensor] = None) -> Tensor:
+        """latents (N,S,D), timesteps (N,S) long, context (N,t,d); ctx_lens (N,) visible context
+        length per row or None.  Diagonal self mask, key padding from ctx_lens shifted by the prepended
+        zero vector; cross_mask None = inference path (S = 1), else the additive (N,1,S,t+1) or (S,t+1)
+        shifted causal mask of the training-shaped forward."""
         cfg, sd, tc = self.cfg, self.sd, self.cfg.denoiser
         emb_t = self.embed_time(timesteps)                                           # :184
         cond = torch.cat([torch.zeros_like(context[:, 0:1]), context], dim=1)        # :193-199
@@ -223,7 +224,7 @@ class OracleTwoTower:
             # cross attention block (:475-521)
             shift, scale, gate = m_x.chunk(3, dim=-1)
             h = norm(x, sd, p + ".cross_attention_layer_norm", tc.norm, cfg.norm_eps) * (1 + scale) + shift
-            x = x + gate * self._mha(p + ".cross_attention", tc, h, cond, key_lens=key_lens,
+            x = x + gate * self._mha(p + ".cross_attention", tc, h, cond, key_lens=key_lens, mask=cross_mask,
                                      use_rope=False)
             # ffn block (:523-546)
             shift, scale, gate = m_ffn.chunk(3, dim=-1)
@@ -231,6 +232,20 @@ class OracleTwoTower:
             x = x + gate * self._ffn(p + ".ffn", tc, h)
         x = norm(x, sd, "denoiser.layer_norm", tc.norm, cfg.norm_eps)                # :243-244
         return linear(x, sd, "denoiser.final_proj.fc")                               # :249
+
+    def forward(self, x_norm: Tensor, noisy: Tensor, timesteps: Tensor, lengths: Optional[Tensor] = None,
+                source_lengths: Optional[Tensor] = None) -> Tensor:
+        """TwoTowerDiffusionLCModel.forward, builder.py:128-159, with cf_guidance_prob = 0: contextualize the clean
+        normalized batch x_norm (N,T,D), then denoise noisy (N,S,D) with per-position timesteps (N,S) under the
+        ShiftedCausalAttentionMask (lcm/nn/denoisers/attention_masks.py:21-46, 196-228): query i sees key j of
+        [zero vector, context] iff j <= i + source_length.  `lengths` (N,) = valid context positions (padding mask)."""
+        context = self.encode(x_norm)
+        S, K = noisy.shape[1], context.shape[1] + 1
+        if source_lengths is None:
+            mask = torch.ones(S, K).tril_(diagonal=0).log()
+        else:
+            mask = torch.stack([torch.ones(S, K).tril_(diagonal=int(n)) for n in source_lengths]).unsqueeze(1).log()
+        return self.denoise(noisy, timesteps, context, ctx_lens=lengths, cross_mask=mask)
 
     # -- generation-time set-up (builder.py:215-242)
     def prep_for_denoising(self, opt) -> None:

@@ -286,3 +286,27 @@ def test_scorer_prediction_equals_first_generated_sentence():
             for t in range(mcl, n):
                 first = gen(x[i:i + 1, :t], max_gen_len=1, noise=nz[t - mcl:t - mcl + 1, i:i + 1])[0][0].seq[-1]
                 assert torch.allclose(scored[i][0].seq[t - mcl], first, atol=1e-5), (mcl, i, t)
+
+
+def test_training_shaped_forward_equals_per_position_inference_denoise():
+    """The all-positions forward under the shifted causal mask gives, at position j, what the inference-path denoiser
+    gives for that latent with the first j context positions (two statements of the same masking)."""
+    cfg, m = _model("mini_two_tower_diffusion_lcm")
+    norm = oracle.load_dummy_normalizer()
+    x = m.normalize(synthetic_prompts(norm, 2, 5))
+    g = torch.Generator().manual_seed(5)
+    noisy = torch.randn(2, 5, x.shape[-1], generator=g)
+    ts = torch.randint(0, 100, (2, 5), generator=g)
+    full = m.forward(x, noisy, ts)
+    ctx = m.encode(x)
+    for j in range(5):
+        # position 0 sees only the zero vector: stated like the unconditional rows of guidance (no visible context)
+        one = (m.denoise(noisy[:, j:j + 1], ts[:, j:j + 1], ctx[:, :j]) if j > 0 else
+               m.denoise(noisy[:, :1], ts[:, :1], ctx[:, :1], ctx_lens=torch.zeros(2, dtype=torch.long)))
+        assert torch.allclose(full[:, j:j + 1], one, atol=1e-4), j
+    # source_lengths move the visible window: with shift s position j sees the first j + s context positions
+    shifted = m.forward(x, noisy, ts, source_lengths=torch.tensor([2, 1]))
+    for b, s in enumerate([2, 1]):
+        for j in range(5):
+            one = m.denoise(noisy[b:b + 1, j:j + 1], ts[b:b + 1, j:j + 1], ctx[b:b + 1, :min(5, j + s)])
+            assert torch.allclose(shifted[b:b + 1, j:j + 1], one, atol=1e-4), (b, j)
