@@ -140,6 +140,8 @@ struct GemmArgs {
     const void* W; const void* W2;
     const void* bias; const void* bias2;
     const float* gate;          // (N,) fp32 or null
+    // RESID with a gate that differs per row: row m reads gate + clamp(gate_rows[m], 0, gate_steps - 1) * gate_stride
+    const int32_t* gate_rows; size_t gate_stride; int gate_steps;
     void* out; int ldo;
     const int32_t* out_rows;    // optional row map for `out` (length M) or null
     // With out_rows: > 0 selects the KV-cache layout [slot][head][position][128] -- a mapped row index

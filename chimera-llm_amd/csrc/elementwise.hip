@@ -273,11 +273,17 @@ __global__ __launch_bounds__(NT) void k_norm_modulate(float* __restrict__ x, con
 template <typename T, int KIND, int NV>
 __global__ __launch_bounds__(256) void k_norm_rows(const float* __restrict__ x, const T* __restrict__ w,
                                                    const T* __restrict__ b, const float* __restrict__ shift,
-                                                   const float* __restrict__ scale, T* __restrict__ y, int rows, float eps) {
+                                                   const float* __restrict__ scale, T* __restrict__ y, int rows, float eps,
+                                                   RowSteps rs) {
     constexpr int dim = NV * 256;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;   // wave-uniform
+    if (rs.row_step != nullptr && scale != nullptr) {   // this row's own entry of the modulation table
+        const size_t moff = (size_t)min(max(rs.row_step[row], 0), rs.n_steps - 1) * rs.step_stride;
+        shift += moff;
+        scale += moff;
+    }
     const float* xr = x + (size_t)row * dim;
     float4 v[NV];
 #pragma unroll
@@ -334,11 +340,11 @@ __global__ __launch_bounds__(256) void k_norm_rows(const float* __restrict__ x, 
 
 template <typename T, int KIND>
 static bool launch_norm_rows(const float* x, const void* w, const void* b, const float* shift, const float* scale, void* y,
-                             int rows, int dim, float eps, hipStream_t st) {
+                             int rows, int dim, float eps, hipStream_t st, const RowSteps& rs) {
     const dim3 grid((rows + 3) / 4), block(256);
 #define LCM_ROWS(NV)                                                                                             \
     hipLaunchKernelGGL((k_norm_rows<T, KIND, NV>), grid, block, 0, st, x, (const T*)w, (const T*)b, shift, scale, \
-                       (T*)y, rows, eps)
+                       (T*)y, rows, eps, rs)
     switch (dim) {
         case 256: LCM_ROWS(1); return true;
         case 1024: LCM_ROWS(4); return true;
@@ -371,14 +377,14 @@ int launch_norm_modulate(float* x, const void* w, const void* b, const float* sh
         rs = *steps;
         LCM_REQUIRE(rs.row_step == nullptr || rs.n_steps >= 1, "norm: per-row steps need a table size");
     }
-    if (!pend && rows >= 1024 && rs.row_step == nullptr) {
+    if (!pend && rows >= 1024) {
         bool done = false;
         if (dtype == LCMHIP_BF16)
-            done = norm_kind == LCMHIP_NORM_RMS ? launch_norm_rows<bf16_t, LCMHIP_NORM_RMS>(x, w, b, shift, scale, y, rows, dim, eps, st)
-                                                : launch_norm_rows<bf16_t, LCMHIP_NORM_LAYERNORM>(x, w, b, shift, scale, y, rows, dim, eps, st);
+            done = norm_kind == LCMHIP_NORM_RMS ? launch_norm_rows<bf16_t, LCMHIP_NORM_RMS>(x, w, b, shift, scale, y, rows, dim, eps, st, rs)
+                                                : launch_norm_rows<bf16_t, LCMHIP_NORM_LAYERNORM>(x, w, b, shift, scale, y, rows, dim, eps, st, rs);
         else if (dtype == LCMHIP_F32)
-            done = norm_kind == LCMHIP_NORM_RMS ? launch_norm_rows<float, LCMHIP_NORM_RMS>(x, w, b, shift, scale, y, rows, dim, eps, st)
-                                                : launch_norm_rows<float, LCMHIP_NORM_LAYERNORM>(x, w, b, shift, scale, y, rows, dim, eps, st);
+            done = norm_kind == LCMHIP_NORM_RMS ? launch_norm_rows<float, LCMHIP_NORM_RMS>(x, w, b, shift, scale, y, rows, dim, eps, st, rs)
+                                                : launch_norm_rows<float, LCMHIP_NORM_LAYERNORM>(x, w, b, shift, scale, y, rows, dim, eps, st, rs);
         if (done) {
             LCM_HIP_CHECK(hipGetLastError());
             return LCMHIP_OK;

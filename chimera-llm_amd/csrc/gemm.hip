@@ -195,7 +195,11 @@ __global__ __launch_bounds__(256) void k_splitk_finish(GemmArgs p, int splits) {
         }
         if constexpr (EPI == LCMHIP_EPI_RESID) {
             float4 g = make_float4(1.f, 1.f, 1.f, 1.f);
-            if (p.gate) g = *reinterpret_cast<const float4*>(p.gate + n);
+            if (p.gate) {
+                const size_t goff = (p.gate_rows != nullptr && m < p.M)
+                                        ? (size_t)min(max(p.gate_rows[m], 0), p.gate_steps - 1) * p.gate_stride : 0;
+                g = *reinterpret_cast<const float4*>(p.gate + goff + n);
+            }
             float4* dstp = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n);
             float4 o = *dstp;
             o.x += g.x * v[0]; o.y += g.y * v[1]; o.z += g.z * v[2]; o.w += g.w * v[3];
@@ -317,6 +321,8 @@ static int check_args(const GemmArgs& a) {
     LCM_REQUIRE(((size_t)a.lda * es) % 16 == 0 && ((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.W % 16) == 0,
                 "gemm: operands must be 16-byte aligned");
     LCM_REQUIRE(a.extra_rows == 0 || (a.epilogue == LCMHIP_EPI_RESID && a.extra_const), "gemm: extra rows need RESID");
+    LCM_REQUIRE(a.gate_rows == nullptr || (a.epilogue == LCMHIP_EPI_RESID && a.gate && a.gate_steps >= 1 && a.extra_rows == 0),
+                "gemm: per-row gates need RESID, a gate table and no extra rows");
     LCM_REQUIRE(a.out_head_cap == 0 || (a.out_rows != nullptr && a.N % 128 == 0), "gemm: the KV-cache layout needs a row map and 128-wide heads");
     return LCMHIP_OK;
 }

@@ -25,6 +25,114 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 }  // namespace
 
+// Epilogue of the 128 x 128 kernel.  In the accumulators a lane holds 4 columns of 16 different rows, so storing
+// from there touches 16 rows x 32..64 bytes per instruction.  Each wave instead passes its 64 x 64 tile through its
+// own piece of the (now idle) staging memory, 32 rows at a time, and stores row-contiguous 128..256-byte segments;
+// bias and activations are applied on the way in, the residual update (read-modify-write) and row maps on the way out.
+template <typename T, int EPI>
+__device__ __forceinline__ void big_epilogue(const GemmArgs& p, const f32x4 (&acc)[4][4], char* smem, int wid,
+                                             int m_wave0, int n_wave0, int split, int lane) {
+    constexpr bool DUAL = (EPI == LCMHIP_EPI_SWIGLU);
+    constexpr int TNO = DUAL ? 2 : 4;            // output column tiles of the wave
+    constexpr int NC = 16 * TNO;                 // output columns of the wave
+    constexpr int LROW = NC + 4;                 // padded row (floats): 16 rows x one 16-byte piece hit 16 bank groups
+    constexpr bool F32OUT = (EPI == EPI_PARTIAL || EPI == LCMHIP_EPI_STORE_F32 || EPI == LCMHIP_EPI_RESID || sizeof(T) == 4);
+    float* tile = reinterpret_cast<float*>(smem) + wid * (32 * 68);
+    const int quad = 4 * (lane >> 4), frow = lane & 15;
+    const T* bias = reinterpret_cast<const T*>(p.bias);
+    const T* bias2 = reinterpret_cast<const T*>(p.bias2);
+    float bv[TNO][4], bv2[TNO][4];
+#pragma unroll
+    for (int tn = 0; tn < TNO; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n_wave0 + tn * 16 + quad + r;
+            bv[tn][r] = (EPI != EPI_PARTIAL && bias) ? Elem<T>::load(bias + n) : 0.f;
+            bv2[tn][r] = (DUAL && bias2) ? Elem<T>::load(bias2 + n) : 0.f;
+        }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();   // every wave is done with the staging buffers / with the previous half's tile
+#pragma unroll
+        for (int tn = 0; tn < TNO; ++tn)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int tm = 2 * half + t;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = acc[tn][tm][r] + bv[tn][r];
+                    if constexpr (EPI == LCMHIP_EPI_RELU) v[r] = fmaxf(v[r], 0.f);
+                    if constexpr (DUAL) {
+                        const float g = v[r];
+                        v[r] = (acc[tn + 2][tm][r] + bv2[tn][r]) * (g / (1.f + __expf(-g)));
+                    }
+                }
+                *reinterpret_cast<float4*>(tile + (16 * t + frow) * LROW + 16 * tn + quad) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        __syncthreads();
+        if constexpr (F32OUT) {
+            constexpr int LPR = NC / 4, RPP = 64 / LPR;     // lanes per row, rows per pass
+            const int c = (lane % LPR) * 4, n = n_wave0 + c;
+            float4 g = make_float4(1.f, 1.f, 1.f, 1.f);
+            if constexpr (EPI == LCMHIP_EPI_RESID) {
+                if (p.gate && !p.gate_rows) g = *reinterpret_cast<const float4*>(p.gate + n);
+            }
+#pragma unroll
+            for (int ps = 0; ps < 32 / RPP; ++ps) {
+                const int r = ps * RPP + lane / LPR;
+                const int m = m_wave0 + 32 * half + r;
+                float4 v = *reinterpret_cast<const float4*>(tile + r * LROW + c);
+                if constexpr (EPI == EPI_PARTIAL) {
+                    if (m < p.M) *reinterpret_cast<float4*>(p.partial + ((size_t)split * p.M + m) * p.N + n) = v;
+                } else if constexpr (EPI == LCMHIP_EPI_RESID) {
+                    const bool real = m < p.M;
+                    const bool extra = !real && m < p.M + p.extra_rows;
+                    if (extra) v = *reinterpret_cast<const float4*>(p.extra_const + n);
+                    if (p.gate_rows != nullptr && real)
+                        g = *reinterpret_cast<const float4*>(p.gate + (size_t)min(max(p.gate_rows[m], 0), p.gate_steps - 1) * p.gate_stride + n);
+                    if (real || extra) {
+                        float4* dstp = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n);
+                        float4 o = *dstp;
+                        o.x += g.x * v.x; o.y += g.y * v.y; o.z += g.z * v.z; o.w += g.w * v.w;
+                        *dstp = o;
+                    }
+                } else {
+                    if (m < p.M) {
+                        size_t oidx;
+                        if (p.out_rows == nullptr) oidx = (size_t)m * p.ldo + n;
+                        else if (p.out_head_cap > 0) oidx = kv_cache_offset(p.out_rows[m], n, p.out_head_cap, p.N);
+                        else oidx = (size_t)p.out_rows[m] * p.ldo + n;
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + oidx) = v;
+                    }
+                }
+            }
+        } else {
+            constexpr int LPR = NC / 8, RPP = 64 / LPR;
+            const int c = (lane % LPR) * 8, n = n_wave0 + c;
+#pragma unroll
+            for (int ps = 0; ps < 32 / RPP; ++ps) {
+                const int r = ps * RPP + lane / LPR;
+                const int m = m_wave0 + 32 * half + r;
+                const float4 a = *reinterpret_cast<const float4*>(tile + r * LROW + c);
+                const float4 b = *reinterpret_cast<const float4*>(tile + r * LROW + c + 4);
+                if (m < p.M) {
+                    size_t oidx;
+                    if (p.out_rows == nullptr) oidx = (size_t)m * p.ldo + n;
+                    else if (p.out_head_cap > 0) oidx = kv_cache_offset(p.out_rows[m], n, p.out_head_cap, p.N);
+                    else oidx = (size_t)p.out_rows[m] * p.ldo + n;
+                    uint4 o;
+                    o.x = (uint32_t)f32_to_bf16(a.x) | ((uint32_t)f32_to_bf16(a.y) << 16);
+                    o.y = (uint32_t)f32_to_bf16(a.z) | ((uint32_t)f32_to_bf16(a.w) << 16);
+                    o.z = (uint32_t)f32_to_bf16(b.x) | ((uint32_t)f32_to_bf16(b.y) << 16);
+                    o.w = (uint32_t)f32_to_bf16(b.z) | ((uint32_t)f32_to_bf16(b.w) << 16);
+                    *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.out) + oidx) = o;
+                }
+            }
+        }
+    }
+}
+
 // WMV wave rows: the tile is (64 * WMV) rows x 128 weight rows, 2 * WMV waves of 64 x 64 each.
 template <int EPI, int WMV>
 __global__ __launch_bounds__(128 * WMV) void k_gemm_big(GemmArgs p) {
@@ -123,8 +231,9 @@ __global__ __launch_bounds__(128 * WMV) void k_gemm_big(GemmArgs p) {
         __builtin_amdgcn_s_setprio(0);
     }
 
-    gemm_epilogue<bf16_t, EPI, 4, 4>(p, acc, m0 + wm * 64, DUAL ? bx * (kBN / 2) + wn * 32 : bx * kBN + wn * 64,
-                                     blockIdx.y, lane);
+    static_assert(2 * STAGE >= NWAVES * 32 * 68 * 4, "the epilogue tiles must fit the staging buffers");
+    big_epilogue<bf16_t, EPI>(p, acc, smem, wid, m0 + wm * 64, DUAL ? bx * (kBN / 2) + wn * 32 : bx * kBN + wn * 64,
+                              blockIdx.y, lane);
 }
 
 // K splits for the split-K (slab) form: enough workgroups for the chip, at least 8 K tiles per split, and the

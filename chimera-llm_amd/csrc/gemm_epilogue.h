@@ -71,6 +71,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x4 (&a
                         const float4 c = *reinterpret_cast<const float4*>(p.extra_const + n);
                         v[0] = c.x; v[1] = c.y; v[2] = c.z; v[3] = c.w;
                     }
+                    if (p.gate_rows != nullptr && real) {
+                        const float4 g = *reinterpret_cast<const float4*>(
+                            p.gate + (size_t)min(max(p.gate_rows[m], 0), p.gate_steps - 1) * p.gate_stride + n);
+                        gv[0] = g.x; gv[1] = g.y; gv[2] = g.z; gv[3] = g.w;
+                    }
                     if (real || extra) {
                         float4* dstp = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n);
                         float4 o = *dstp;

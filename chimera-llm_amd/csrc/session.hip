@@ -414,9 +414,12 @@ static void gemm_cost(const GemmArgs& a, double out_es, double* bytes, double* f
 static int gemm(lcmhip_session* s, const char* tag, const void* A, int lda, const Lin& W, const Lin* W2,
                 const float* gate, void* out, int ldo, int M, int epi, hipStream_t st,
                 const int32_t* out_rows = nullptr, int extra_rows = 0, const float* extra_const = nullptr,
-                int out_head_cap = 0) {
+                int out_head_cap = 0, const RowSteps* gate_steps = nullptr) {
     GemmArgs a = gemm_args(s, A, lda, W, W2, M, epi);
     a.gate = gate;
+    if (gate_steps && gate_steps->row_step) {
+        a.gate_rows = gate_steps->row_step; a.gate_stride = gate_steps->step_stride; a.gate_steps = gate_steps->n_steps;
+    }
     a.out = out; a.ldo = ldo; a.out_rows = out_rows; a.out_head_cap = out_head_cap;
     a.extra_rows = extra_rows; a.extra_const = extra_const;
     a.partial = s->slab_q; a.partial_bytes = s->slab_bytes;
@@ -1064,20 +1067,22 @@ int lcmhip_denoise_positions(lcmhip_session* s, const float* noisy, const int32_
                 hipLaunchKernelGGL((k_normalize_gather<float>), dim3(R), dim3(128), 0, st, xg, (const float*)nullptr,
                                    (const float*)nullptr, (float*)s->act_in, D, sc, n_positions, j0, 0, 1.0f);
             LCM_HIP_CHECK(hipGetLastError());
-            Pending pend;
-            LCM_TRY(gemm_pending(s, "pos.initial_proj", s->act_in, D, m->init_proj, nullptr, R, &pend, st));
-            pend.init = 1;
+            // The residual stream is updated by the projections' own epilogues (x += gate[row's step] * (h W^T + b)):
+            // with many rows no K split is needed, so nothing has to wait in a slab for the next norm kernel.
+            LCM_TRY(gemm(s, "pos.initial_proj", s->act_in, D, m->init_proj, nullptr, nullptr, s->xres, dm, R, LCMHIP_EPI_STORE_F32, st));
             for (int l = 0; l < L; ++l) {
                 const DenLayer& Ly = m->den[l];
                 const float* mod = s->mod_table + (size_t)l * 9 * dm;   // step 0; rows add their own step offset
-                LCM_TRY(norm(s, "pos.norm_mod", s->xres, Ly.sa_norm, mod, mod + dm, s->act_a, R, R, td.norm_kind, &pend, st, &rs));
+                LCM_TRY(norm(s, "pos.norm_mod", s->xres, Ly.sa_norm, mod, mod + dm, s->act_a, R, R, td.norm_kind, nullptr, st, &rs));
                 if (Ly.ov.w != nullptr) {
-                    LCM_TRY(gemm_pending(s, "pos.self_ov", s->act_a, dm, Ly.ov, mod + 2 * dm, R, &pend, st));
+                    LCM_TRY(gemm(s, "pos.self_ov", s->act_a, dm, Ly.ov, nullptr, mod + 2 * dm, s->xres, dm, R, LCMHIP_EPI_RESID, st,
+                                 nullptr, 0, nullptr, 0, &rs));
                 } else {
                     LCM_TRY(gemm(s, "pos.self_v", s->act_a, dm, Ly.sa.v, nullptr, nullptr, s->act_v, dm, R, LCMHIP_EPI_STORE, st));
-                    LCM_TRY(gemm_pending(s, "pos.self_o", s->act_v, dm, Ly.sa.o, mod + 2 * dm, R, &pend, st));
+                    LCM_TRY(gemm(s, "pos.self_o", s->act_v, dm, Ly.sa.o, nullptr, mod + 2 * dm, s->xres, dm, R, LCMHIP_EPI_RESID, st,
+                                 nullptr, 0, nullptr, 0, &rs));
                 }
-                LCM_TRY(norm(s, "pos.norm_mod", s->xres, Ly.ca_norm, mod + 3 * dm, mod + 4 * dm, s->act_a, R, R, td.norm_kind, &pend, st, &rs));
+                LCM_TRY(norm(s, "pos.norm_mod", s->xres, Ly.ca_norm, mod + 3 * dm, mod + 4 * dm, s->act_a, R, R, td.norm_kind, nullptr, st, &rs));
                 LCM_TRY(gemm(s, "pos.cross_q", s->act_a, dm, Ly.ca.q, nullptr, nullptr, s->act_q, dm, R, LCMHIP_EPI_STORE, st));
                 {
                     AttnQ qa{};
@@ -1087,13 +1092,14 @@ int lcmhip_denoise_positions(lcmhip_session* s, const float* noisy, const int32_
                     LCM_TRY(launch_attention_q(qa, s->cross_k + l * cross_layer, s->cross_v + l * cross_layer, slots, s->act_o, n, sc,
                                                td.num_heads, s->cap + 1, j0, 1, d.dtype, st, nullptr, &win));
                 }
-                LCM_TRY(gemm_pending(s, "pos.cross_o", s->act_o, dm, Ly.ca.o, mod + 5 * dm, R, &pend, st));
-                LCM_TRY(norm(s, "pos.norm_mod", s->xres, Ly.ffn_norm, mod + 6 * dm, mod + 7 * dm, s->act_a, R, R, td.norm_kind, &pend, st, &rs));
+                LCM_TRY(gemm(s, "pos.cross_o", s->act_o, dm, Ly.ca.o, nullptr, mod + 5 * dm, s->xres, dm, R, LCMHIP_EPI_RESID, st,
+                             nullptr, 0, nullptr, 0, &rs));
+                LCM_TRY(norm(s, "pos.norm_mod", s->xres, Ly.ffn_norm, mod + 6 * dm, mod + 7 * dm, s->act_a, R, R, td.norm_kind, nullptr, st, &rs));
                 LCM_TRY(ffn_in(s, "pos.ffn_in", td, Ly.ffn, s->act_a, R, st));
-                LCM_TRY(gemm_pending(s, "pos.ffn_out", s->act_h, td.ffn_dim, Ly.ffn.out, mod + 8 * dm, R, &pend, st));
+                LCM_TRY(gemm(s, "pos.ffn_out", s->act_h, td.ffn_dim, Ly.ffn.out, nullptr, mod + 8 * dm, s->xres, dm, R, LCMHIP_EPI_RESID, st,
+                             nullptr, 0, nullptr, 0, &rs));
             }
-            // final norm: no modulation, but the last gate is still the row's own
-            LCM_TRY(norm(s, "pos.norm_mod", s->xres, m->den_final, nullptr, nullptr, s->act_a, R, R, td.norm_kind, &pend, st, &rs));
+            LCM_TRY(norm(s, "pos.norm_mod", s->xres, m->den_final, nullptr, nullptr, s->act_a, R, R, td.norm_kind, nullptr, st));
             LCM_TRY(gemm(s, "pos.final_proj", s->act_a, dm, m->final_proj, nullptr, nullptr, s->f32tmp, D, R, LCMHIP_EPI_STORE_F32, st));
             float* g_out = out + (size_t)d0 * n_positions * D;
             if (d.dtype == LCMHIP_BF16)
