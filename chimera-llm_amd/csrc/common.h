@@ -154,6 +154,7 @@ struct GemmArgs {
     int extra_rows; const float* extra_const;
     // split-K: fp32 slab [splits][M][N] (optional; without it the K range is never split)
     float* partial; size_t partial_bytes; int max_splits;
+    int tiles_x, tiles_y;       // filled by the launcher of the 256 x 256 kernel (tile grid behind its 1-D launch)
 };
 // C = A W^T with the epilogue applied (split-K + finishing pass when a.partial is given and it pays).
 int launch_gemm(const GemmArgs& a, hipStream_t st);

@@ -12,6 +12,7 @@
 // workgroup per CU and a counted vmcnt across a bare s_barrier measured 20-25 % slower than two stages with two
 // workgroups per CU.)
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "gemm_epilogue.h"
@@ -25,12 +26,12 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 }  // namespace
 
-// Epilogue of the 128 x 128 kernel.  In the accumulators a lane holds 4 columns of 16 different rows, so storing
-// from there touches 16 rows x 32..64 bytes per instruction.  Each wave instead passes its 64 x 64 tile through its
-// own piece of the (now idle) staging memory, 32 rows at a time, and stores row-contiguous 128..256-byte segments;
+// Epilogue of the many-row kernels.  In the accumulators a lane holds 4 columns of 16 different rows, so storing
+// from there touches 16 rows x 32..64 bytes per instruction.  Each wave instead passes its (16 TM) x 64 tile through
+// its own piece of the (now idle) staging memory, 32 rows at a time, and stores row-contiguous 128..256-byte segments;
 // bias and activations are applied on the way in, the residual update (read-modify-write) and row maps on the way out.
-template <typename T, int EPI>
-__device__ __forceinline__ void big_epilogue(const GemmArgs& p, const f32x4 (&acc)[4][4], char* smem, int wid,
+template <typename T, int EPI, int TM>
+__device__ __forceinline__ void big_epilogue(const GemmArgs& p, const f32x4 (&acc)[4][TM], char* smem, int wid,
                                              int m_wave0, int n_wave0, int split, int lane) {
     constexpr bool DUAL = (EPI == LCMHIP_EPI_SWIGLU);
     constexpr int TNO = DUAL ? 2 : 4;            // output column tiles of the wave
@@ -51,8 +52,8 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& p, const f32x4 (&ac
             bv2[tn][r] = (DUAL && bias2) ? Elem<T>::load(bias2 + n) : 0.f;
         }
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        __syncthreads();   // every wave is done with the staging buffers / with the previous half's tile
+    for (int half = 0; half < TM / 2; ++half) {
+        __syncthreads();   // every wave is done with the staging buffers / with the previous round's tile
 #pragma unroll
         for (int tn = 0; tn < TNO; ++tn)
 #pragma unroll
@@ -232,8 +233,232 @@ __global__ __launch_bounds__(128 * WMV) void k_gemm_big(GemmArgs p) {
     }
 
     static_assert(2 * STAGE >= NWAVES * 32 * 68 * 4, "the epilogue tiles must fit the staging buffers");
-    big_epilogue<bf16_t, EPI>(p, acc, smem, wid, m0 + wm * 64, DUAL ? bx * (kBN / 2) + wn * 32 : bx * kBN + wn * 64,
+    big_epilogue<bf16_t, EPI, 4>(p, acc, smem, wid, m0 + wm * 64, DUAL ? bx * (kBN / 2) + wn * 32 : bx * kBN + wn * 64,
                               blockIdx.y, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 256 x 256 tile, 8 waves (2 along the activation rows x 4 along the weight rows; a wave owns 128 x 64 outputs =
+// 8 x 4 accumulator tiles), K step 64, one workgroup per CU, for problems with at least about one tile per CU.
+// The 128 KB of LDS hold two K tiles, each as four 16-KB half-tiles (activation rows 0-127 / 128-255, weight
+// rows 0-127 / 128-255; same swizzled lane-linear image as above).  A K tile is consumed in four phases of 16
+// matrix-core instructions: phase i multiplies the wave's activation row tiles 2 i, 2 i + 1 by all four of its
+// weight row tiles.  The weight fragments of a K tile stay in registers for its four phases.  A phase issues half of
+// its products, then the LDS reads of the NEXT phase's activation fragments and the DMA of one half-tile, then the
+// other half of its products (the reads have eight products to land behind):
+//   phase 0: read X(1)              | DMA X-half 1 of tile t+1
+//   phase 1: barrier A, read X(2)   | DMA W-half 0 of tile t+2 (into the buffer being consumed)
+//   phase 2: read X(3)              | DMA W-half 1 of tile t+2
+//   phase 3: wait: at most those two W half-tiles pending and no LDS read pending; barrier B;
+//            DMA X-half 0 of tile t+2; read X(0) and the weight fragments of tile t+1 (weight tiles 2-3 in place
+//            behind their last products, tiles 0-1 through spare registers).
+// Hazards: the weight halves of a buffer are refilled only after barrier A, which a wave reaches with its weight
+// fragments of that K tile consumed by phase 0's products; the activation halves only after barrier B, which every
+// wave passes with no LDS read pending; a K tile is read only after the counted wait of phase 3 plus barrier B.
+// The DMA of a half-tile is in flight for three to six phases, across the barriers.
+// Measured on the SwiGLU projection 4096 x (2 x 5632) x 2048: 1.07 PFLOP/s against 0.91 for the 128 x 128 kernel;
+// variants that read all fragments in two phases (0.96), that keep four barriers per K tile (1.00), an XCD-banded
+// versus a plain tile order (equal) and DMA issue staggered between the two waves of a SIMD (+1 %) were measured too.
+// ------------------------------------------------------------------------------------------------
+constexpr int kHT = 128 * kRowB;          // one half-tile: 128 rows x 128 bytes
+constexpr int kBig256Lds = 2 * 4 * kHT;   // 128 KB
+
+template <int EPI>
+__global__ __launch_bounds__(512) void k_gemm_big256(GemmArgs p) {
+    constexpr bool DUAL = (EPI == LCMHIP_EPI_SWIGLU);
+    extern __shared__ __attribute__((aligned(1024))) char smem256[];
+    char* const smem = smem256;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 2, wc = wid & 3;
+    // Tile order.  Workgroup ids go round-robin over the 8 XCDs (each with its own L2), so XCD x runs ids x, x + 8, ...
+    // in order.  Each XCD gets one contiguous piece of a band-major tile order (bands of 2 activation-row tiles, weight
+    // tiles inside): the 32 tiles it runs at a time share 2 activation tiles and 16 weight tiles through its L2.
+    int bx, by;
+    {
+        const int nx = p.tiles_x, ny = p.tiles_y, T = nx * ny;
+        const int id = blockIdx.x, xcd = id & 7, q = T >> 3, r = T & 7;
+        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+        const int band = L / (2 * nx), rem = L - band * 2 * nx;
+        const int rows = min(2, ny - 2 * band);
+        bx = rem / rows;
+        by = 2 * band + rem % rows;
+    }
+    const int m0 = by * 256;
+    const uint32_t kbytes = (uint32_t)p.K * 2;
+    const int nk = p.K / 64;
+
+    // staging: a half-tile takes two DMA instructions per lane; in round j wave w fills rows 8 (8 j + w) .. + 7,
+    // lane -> (row lane / 8, slot lane % 8); slot s of row r holds K piece s ^ ((r / 2) % 8), and for these rows
+    // (r / 2) % 8 = 4 (w % 2) + (lane / 8) / 2 in both rounds.
+    const int srow = lane >> 3;
+    const uint32_t piece_off = (uint32_t)(((lane & 7) ^ ((4 * (wid & 1) + (srow >> 1)) & 7)) * 16);
+    uint32_t offX[2][2], offW[2][2];   // [half][round] byte offsets from p.A / p.W (p.W2)
+    bool w2[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = (8 * j + wid) * 8 + srow;      // row inside the half-tile
+            int m = m0 + 128 * h + r;
+            m = m < p.M ? m : p.M - 1;                   // rows past the end repeat the last row; never stored
+            offX[h][j] = (uint32_t)m * (uint32_t)p.lda * 2u + piece_off;
+            const int t = 128 * h + r;                   // weight row inside the tile
+            w2[h][j] = false;
+            if constexpr (DUAL) {
+                // wave column t / 64 owns 32 gate rows followed by 32 inner rows of the same 32 outputs
+                const int wcol = t >> 6, rr = t & 63;
+                offW[h][j] = (uint32_t)(bx * 128 + wcol * 32 + (rr & 31)) * kbytes + piece_off;
+                w2[h][j] = rr >= 32;
+            } else {
+                offW[h][j] = (uint32_t)(bx * 256 + t) * kbytes + piece_off;
+            }
+        }
+    const char* const Ab = reinterpret_cast<const char*>(p.A);
+    const char* const Wb = reinterpret_cast<const char*>(p.W);
+    const char* const W2b = reinterpret_cast<const char*>(p.W2);
+    auto stage_x = [&](int h, int kt, int buf) {
+        char* dst = smem + buf * (4 * kHT) + h * kHT + wid * 1024;
+        const uint32_t koff = (uint32_t)kt * kRowB;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)(Ab + offX[h][j] + koff), (lptr_t)(dst + j * 8192), 16, 0, 0);
+    };
+    auto stage_w = [&](int h, int kt, int buf) {
+        char* dst = smem + buf * (4 * kHT) + (2 + h) * kHT + wid * 1024;
+        const uint32_t koff = (uint32_t)kt * kRowB;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const char* base = (DUAL && w2[h][j]) ? W2b : Wb;
+            __builtin_amdgcn_global_load_lds((gptr_t)(base + offW[h][j] + koff), (lptr_t)(dst + j * 8192), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment addresses inside a K tile's 64 KB: row = base + lane % 16, K piece of k-step ks = 4 ks + lane / 16
+    const int frow = lane & 15;
+    const int fsw = (frow >> 1) & 7;
+    const int x_off = wr * kHT + frow * kRowB;                               // + 16 tm rows
+    const int w_off = (2 + (wc >> 1)) * kHT + ((wc & 1) * 64 + frow) * kRowB;   // + 16 tn rows
+    const int slot0 = (((lane >> 4)) ^ fsw) * 16, slot1 = ((4 + (lane >> 4)) ^ fsw) * 16;
+
+    // prologue: K tile 0 whole; of K tile 1 the weight halves and activation half 0 (nk >= 4: K is a multiple of 256)
+    stage_w(0, 0, 0); stage_w(1, 0, 0); stage_x(0, 0, 0); stage_x(1, 0, 0);
+    stage_w(0, 1, 1); stage_w(1, 1, 1); stage_x(0, 1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // fragments: w[ks][tn] = the wave's 64 weight rows; x?[ks][b] = activation row tiles 2 i + b of phase i
+#define LCM_RD_W2(BASE, TN0)                                                                               \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                        \
+        w[0][TN0 + a] = *reinterpret_cast<const bf16x8*>((BASE) + w_off + (TN0 + a) * 16 * kRowB + slot0); \
+        w[1][TN0 + a] = *reinterpret_cast<const bf16x8*>((BASE) + w_off + (TN0 + a) * 16 * kRowB + slot1); \
+    }
+#define LCM_RD_X2(DST, BASE, I)                                                                            \
+    _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                        \
+        DST[0][b] = *reinterpret_cast<const bf16x8*>((BASE) + x_off + (2 * (I) + b) * 16 * kRowB + slot0); \
+        DST[1][b] = *reinterpret_cast<const bf16x8*>((BASE) + x_off + (2 * (I) + b) * 16 * kRowB + slot1); \
+    }
+    // 8 products: weight tiles TN0, TN0 + 1 x the phase's two activation tiles x both k-steps
+#define LCM_MMA8(TN0, XF, I)                                                                               \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                       \
+        _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                      \
+            _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                  \
+                acc[TN0 + a][2 * (I) + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ks][TN0 + a], XF[ks][b], acc[TN0 + a][2 * (I) + b], 0, 0, 0);
+
+    bf16x8 w[2][4], xe[2][2], xo[2][2];
+    LCM_RD_X2(xe, smem, 0)
+    LCM_RD_W2(smem, 0)
+    LCM_RD_W2(smem, 2)
+    // one K tile; MORE1 / MORE2: K tiles kt + 1 / kt + 2 exist (compile-time: the loop body has no branches).
+    // hipcc waits for EVERY outstanding LDS read whenever a product needs one, so each phase first issues the half
+    // of its products whose operands were read a phase ago, and only then the reads for the next phase.
+#define LCM_PIN() __builtin_amdgcn_sched_barrier(0)
+    auto tile = [&](int kt, auto more1_t, auto more2_t) {
+        constexpr bool more1 = decltype(more1_t)::value, more2 = decltype(more2_t)::value;
+        const int buf = kt & 1;
+        const char* base = smem + buf * (4 * kHT);
+        const char* nbase = smem + (buf ^ 1) * (4 * kHT);
+        // ---- phase 0
+        __builtin_amdgcn_s_setprio(1);
+        LCM_MMA8(0, xe, 0)
+        __builtin_amdgcn_s_setprio(0);
+        LCM_PIN();
+        LCM_RD_X2(xo, base, 1)
+        if constexpr (more1) stage_x(1, kt + 1, buf ^ 1);
+        LCM_PIN();
+        __builtin_amdgcn_s_setprio(1);
+        LCM_MMA8(2, xe, 0)
+        __builtin_amdgcn_s_setprio(0);
+        // ---- phase 1: every wave has consumed its weight fragments of this K tile -> barrier A frees the weight halves
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+        LCM_MMA8(0, xo, 1)
+        __builtin_amdgcn_s_setprio(0);
+        LCM_PIN();
+        LCM_RD_X2(xe, base, 2)
+        if constexpr (more2) stage_w(0, kt + 2, buf);
+        LCM_PIN();
+        __builtin_amdgcn_s_setprio(1);
+        LCM_MMA8(2, xo, 1)
+        __builtin_amdgcn_s_setprio(0);
+        // ---- phase 2
+        __builtin_amdgcn_s_setprio(1);
+        LCM_MMA8(0, xe, 2)
+        __builtin_amdgcn_s_setprio(0);
+        LCM_PIN();
+        LCM_RD_X2(xo, base, 3)
+        if constexpr (more2) stage_w(1, kt + 2, buf);
+        LCM_PIN();
+        __builtin_amdgcn_s_setprio(1);
+        LCM_MMA8(2, xe, 2)
+        __builtin_amdgcn_s_setprio(0);
+        // ---- phase 3: K tile kt + 1 has landed (at most the two weight half-tiles of kt + 2 pending), all reads of
+        // this buffer's activation halves are complete -> barrier B; then the next tile's fragments: weight tiles
+        // 2-3 in place behind their last products, weight tiles 0-1 into spare registers
+        if constexpr (more2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if constexpr (more2) stage_x(0, kt + 2, buf);
+        __builtin_amdgcn_s_setprio(1);
+        LCM_MMA8(2, xo, 3)
+        __builtin_amdgcn_s_setprio(0);
+        LCM_PIN();
+        bf16x8 wn[2][2];
+        if constexpr (more1) {
+            LCM_RD_X2(xe, nbase, 0)
+            LCM_RD_W2(nbase, 2)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                wn[0][a] = *reinterpret_cast<const bf16x8*>(nbase + w_off + a * 16 * kRowB + slot0);
+                wn[1][a] = *reinterpret_cast<const bf16x8*>(nbase + w_off + a * 16 * kRowB + slot1);
+            }
+        }
+        LCM_PIN();
+        __builtin_amdgcn_s_setprio(1);
+        LCM_MMA8(0, xo, 3)
+        __builtin_amdgcn_s_setprio(0);
+        if constexpr (more1) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) { w[0][a] = wn[0][a]; w[1][a] = wn[1][a]; }
+        }
+    };
+    using yes = std::true_type;
+    using no = std::false_type;
+    for (int kt = 0; kt < nk - 2; ++kt) tile(kt, yes{}, yes{});
+    tile(nk - 2, yes{}, no{});
+    tile(nk - 1, no{}, no{});
+#undef LCM_PIN
+#undef LCM_RD_W2
+#undef LCM_RD_X2
+#undef LCM_MMA8
+
+    big_epilogue<bf16_t, EPI, 8>(p, acc, smem, wid, m0 + wr * 128, DUAL ? bx * 128 + wc * 32 : bx * 256 + wc * 64, 0, lane);
 }
 
 // K splits for the split-K (slab) form: enough workgroups for the chip, at least 8 K tiles per split, and the
@@ -258,7 +483,46 @@ bool gemm_big_applicable(const GemmArgs& a, bool may_split) {
 }
 
 // epi: LCMHIP_EPI_* or EPI_PARTIAL; splits >= 1 (only with EPI_PARTIAL); m_rows: rows the row tiles must cover
+// The 256 x 256 kernel needs about one tile per CU, no K split, and 32-bit operand offsets.
+static bool big256_applicable(const GemmArgs& a, int epi, int splits, int m_rows) {
+    static const int mode = [] { const char* e = getenv("LCMHIP_BIG256"); return e ? atoi(e) : 1; }();
+    static const int min_tiles = [] { const char* e = getenv("LCMHIP_BIG256_MIN_TILES"); return e ? atoi(e) : 224; }();
+    if (mode == 0 || splits != 1 || epi == EPI_PARTIAL) return false;
+    const int wrows = epi == LCMHIP_EPI_SWIGLU ? 2 * a.N : a.N;
+    if (wrows % 256 != 0 || a.K % 64 != 0 || a.K < 128) return false;
+    if ((size_t)a.M * a.lda * 2 >= (1ull << 31) || (size_t)wrows * a.K * 2 >= (1ull << 31)) return false;
+    const int tiles = (wrows / 256) * ((m_rows + 255) / 256);
+    return tiles >= min_tiles;
+}
+
+static int launch_gemm_big256(const GemmArgs& a_in, int epi, int m_rows, hipStream_t st) {
+    const int wrows = epi == LCMHIP_EPI_SWIGLU ? 2 * a_in.N : a_in.N;
+    GemmArgs a = a_in;
+    a.tiles_x = wrows / 256;
+    a.tiles_y = (m_rows + 255) / 256;
+    dim3 grid(a.tiles_x * a.tiles_y), block(512);
+#define LCM_BIG256(E)                                                                                              \
+    {                                                                                                              \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_big256<E>),       \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kBig256Lds); \
+        LCM_HIP_CHECK(attr);                                                                                       \
+        hipLaunchKernelGGL((k_gemm_big256<E>), grid, block, kBig256Lds, st, a);                                    \
+    }
+    switch (epi) {
+        case LCMHIP_EPI_STORE: LCM_BIG256(LCMHIP_EPI_STORE); break;
+        case LCMHIP_EPI_STORE_F32: LCM_BIG256(LCMHIP_EPI_STORE_F32); break;
+        case LCMHIP_EPI_RELU: LCM_BIG256(LCMHIP_EPI_RELU); break;
+        case LCMHIP_EPI_SWIGLU: LCM_BIG256(LCMHIP_EPI_SWIGLU); break;
+        case LCMHIP_EPI_RESID: LCM_BIG256(LCMHIP_EPI_RESID); break;
+        default: return fail(LCMHIP_ERR_INVALID, "gemm: unknown epilogue");
+    }
+#undef LCM_BIG256
+    LCM_HIP_CHECK(hipGetLastError());
+    return LCMHIP_OK;
+}
+
 int launch_gemm_big(const GemmArgs& a, int epi, int splits, int m_rows, hipStream_t st) {
+    if (big256_applicable(a, epi, splits, m_rows)) return launch_gemm_big256(a, epi, m_rows, st);
     const int wrows = epi == LCMHIP_EPI_SWIGLU ? 2 * a.N : a.N;
     // (256 x 128 tiles with 8 waves and one workgroup per CU measured 10-20 % slower than two 128 x 128 workgroups.)
     dim3 grid(wrows / kBN, splits, (m_rows + kBM - 1) / kBM), block(256);

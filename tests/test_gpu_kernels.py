@@ -106,6 +106,27 @@ def test_gemm_many_rows(hip, M, N, K, split):
     _check_epilogues(hip, torch.bfloat16, M, N, K, split)
 
 
+@pytest.mark.parametrize("M", [2049, 3000])
+@pytest.mark.parametrize("K", [256, 768, 2048])
+def test_gemm_one_tile_per_cu(hip, M, K):
+    """Enough 256 x 256 tiles for every CU (>= 224): the 8-wave kernel whose LDS-DMA stays in flight across
+    barriers; K = 256 is the shortest pipeline the interface allows (4 K tiles), M is ragged against the 256-row tile."""
+    _check_epilogues(hip, torch.bfloat16, M, 6400, K, False)
+
+
+def test_gemm_one_tile_per_cu_identity(hip):
+    """A = I against an asymmetric integer W (exact in bf16): catches a wrong fragment, quadrant or half-tile map
+    of the 256 x 256 kernel exactly, and a stale or early LDS read as a wrong integer."""
+    M = K = N = 4096
+    A = torch.eye(M, K).cuda().to(torch.bfloat16)
+    W = (torch.arange(N).view(N, 1) % 7 - 3 + 2 * (torch.arange(K).view(1, K) % 5)).float().cuda().to(torch.bfloat16)
+    want = W.float().cpu().T
+    for _ in range(3):
+        out = torch.full((M, N), float("nan"), device="cuda")
+        _gemm(hip, A, W, None, None, None, None, out, hip.EPI_STORE_F32)
+        assert torch.equal(out.cpu(), want)
+
+
 def test_gemm_many_rows_identity_and_row_map(hip):
     """A = I against an asymmetric integer W (exact in bf16) through the 128 x 128 kernel, plain and scattered
     through a row map into the (slot, head, position, 128) cache layout."""
