@@ -235,6 +235,12 @@ struct Plan {
     int n_tiles, m_tiles, splits;
 };
 
+// 0: register-staged kernels only; 1: LDS-DMA staging for the 128-row bf16 tile; 2 (default): also for the 64-row tile
+static int dma_mode() {
+    static const int v = [] { const char* e = getenv("LCMHIP_GEMM_DMA"); return e ? atoi(e) : 2; }();
+    return v;
+}
+
 static int tall_mode() {
     static const int v = [] { const char* e = getenv("LCMHIP_TALL"); return e ? atoi(e) : 1; }();   // 0: 64 x 64 tiles only; 1 (default): 128 x 64 tiles with 8 waves for more than 64 rows
     return v;
@@ -262,6 +268,9 @@ static Plan make_plan(const GemmArgs& a, bool may_split) {
         const int target = pl.wm == 4 ? target1 : target2;   // the tall tile fits once per CU
         int s = (target + tiles - 1) / tiles;
         s = std::min(s, nchunks);
+        // the LDS-DMA tall tile wants at least two 512-byte chunks per split (four stages of its pipeline):
+        // measured 10.6 -> 10.1 us on 128 x 2048 x 2048; the 64-row tile is faster with one (7.1 vs 7.7 us)
+        if (pl.wm == 4 && a.dtype == LCMHIP_BF16 && dma_mode() != 0) s = std::min(s, std::max(1, nchunks / 2));
         s = std::min(s, a.max_splits > 0 ? a.max_splits : 64);
         pl.splits = std::max(1, s);
         // re-balance: every split gets the same number of chunks where possible
@@ -269,6 +278,144 @@ static Plan make_plan(const GemmArgs& a, bool may_split) {
         pl.splits = (nchunks + cps - 1) / cps;
     }
     return pl;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The 128 x 64 tile (8 waves) for bf16 with LDS-DMA staging: 256-byte K chunks go global -> LDS directly
+// (global_load_lds, 16 bytes per lane; one instruction fills 4 tile rows), three stages, the DMA two chunks ahead of
+// the matrix cores across one raw barrier per chunk -- no staging registers and no LDS store instructions.
+// The LDS image is lane-linear, so bank conflicts of the fragment reads (16 rows x one 16-byte piece) are removed on
+// the SOURCE side: slot s of tile row r holds K piece s ^ (r % 16).
+// ------------------------------------------------------------------------------------------------
+constexpr int kDmaChunk = 256;                       // bytes of K per tile row and stage
+constexpr int dma_stage_bytes(int wm) { return (32 * wm + 64) * kDmaChunk; }   // activation rows + 64 weight rows
+constexpr int dma_lds_bytes(int wm) { return 3 * dma_stage_bytes(wm); }         // 144 KB (128 rows) / 96 KB (64 rows)
+typedef const __attribute__((address_space(1))) void* dma_gptr_t;
+typedef __attribute__((address_space(3))) void* dma_lptr_t;
+
+// WM wave rows: (32 WM) activation rows x 64 weight rows per workgroup of 2 WM waves.
+template <int EPI, int WM>
+__global__ __launch_bounds__(128 * WM) void k_gemm_dma(GemmArgs p) {
+    constexpr bool DUAL = (EPI == LCMHIP_EPI_SWIGLU);
+    constexpr int NW = 2 * WM;                       // waves
+    constexpr int BM = 32 * WM;                      // activation rows
+    constexpr int XG = BM / 4;                       // row groups (4 rows) of the activation part
+    constexpr int NG = (BM + 64) / 4 / NW;           // row groups per wave and stage
+    constexpr int XJ = XG / NW;                      // ... of which activation groups
+    constexpr int kDmaStage = dma_stage_bytes(WM);
+    extern __shared__ __attribute__((aligned(1024))) char smem_dma[];
+    char* const smem = smem_dma;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wn = wid & 1, wm = wid >> 1;           // 4 x 2 waves, 32 activation rows x 32 weight rows each
+    const int m0 = blockIdx.z * BM;
+    const uint32_t kbytes = (uint32_t)p.K * 2;
+    const int nch512 = (int)(kbytes / kChunkBytes);
+    const int cps = (nch512 + (int)gridDim.y - 1) / (int)gridDim.y;      // 512-byte chunks per split, as planned
+    const int c_begin = 2 * blockIdx.y * cps, c_end = 2 * min(nch512, (int)(blockIdx.y + 1) * cps);   // in 256-byte chunks
+    const int nc = c_end - c_begin;
+
+    // staging: row group g = 4 tile rows; wave w fills groups w, w + NW, ...: first the activation rows, then the
+    // weight rows.  Lane -> (row lane / 16 of the group, slot lane % 16); for every group of this wave the tile row r
+    // has r % 16 = 4 (w % 4) + lane / 16 (NW is a multiple of 4).
+    const int srow = lane >> 4;
+    const uint32_t piece_off = (uint32_t)(((lane & 15) ^ (4 * (wid & 3) + srow)) * 16) + (uint32_t)c_begin * kDmaChunk;
+    const char* src[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        const int g = wid + NW * j;
+        if (j < XJ) {
+            int m = m0 + 4 * g + srow;
+            m = m < p.M ? m : p.M - 1;               // rows past the end repeat the last row; never stored
+            src[j] = reinterpret_cast<const char*>(p.A) + (size_t)m * p.lda * 2 + piece_off;
+        } else {
+            const int t = 4 * (g - XG) + srow;       // weight row inside the tile, 0..63
+            if constexpr (DUAL) {
+                // wave column t / 32 owns 16 gate rows followed by 16 inner rows of the same 16 outputs
+                const int wcol = t >> 5, rr = t & 31;
+                const size_t row = (size_t)blockIdx.x * 32 + wcol * 16 + (rr & 15);
+                src[j] = reinterpret_cast<const char*>(rr < 16 ? p.W : p.W2) + row * kbytes + piece_off;
+            } else {
+                src[j] = reinterpret_cast<const char*>(p.W) + ((size_t)blockIdx.x * 64 + t) * kbytes + piece_off;
+            }
+        }
+    }
+    auto stage = [&](int c, int buf) {
+        char* dst = smem + buf * kDmaStage + wid * 1024;
+        const uint32_t koff = (uint32_t)c * kDmaChunk;
+#pragma unroll
+        for (int j = 0; j < NG; ++j)
+            __builtin_amdgcn_global_load_lds((dma_gptr_t)(src[j] + koff), (dma_lptr_t)(dst + j * NW * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, kq = lane >> 4;
+    const int x_off = (wm * 32 + frow) * kDmaChunk;
+    const int w_off = (BM + wn * 32 + frow) * kDmaChunk;
+
+    stage(0, 0);
+    if (nc > 1) stage(1, 1);
+    for (int c = 0; c < nc; ++c) {
+        // chunk c has landed (this wave's part: everything but the NG newest DMA instructions = chunk c + 1) ...
+        if (c + 1 < nc) {
+            if constexpr (NG == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        // ... for every wave, and every wave is done with chunk c - 1, whose stage is refilled next
+        __builtin_amdgcn_s_barrier();
+        if (c + 2 < nc) stage(c + 2, (c + 2) % 3);
+        const char* base = smem + (c % 3) * kDmaStage;
+        bf16x8 w[4][2], x[4][2];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int slot = ((4 * ks + kq) ^ frow) * 16;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) w[ks][t] = *reinterpret_cast<const bf16x8*>(base + w_off + t * 16 * kDmaChunk + slot);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) x[ks][t] = *reinterpret_cast<const bf16x8*>(base + x_off + t * 16 * kDmaChunk + slot);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ks][tn], x[ks][tm], acc[tn][tm], 0, 0, 0);
+    }
+    gemm_epilogue<bf16_t, EPI, 2, 2>(p, acc, m0 + wm * 32, DUAL ? blockIdx.x * 32 + wn * 16 : blockIdx.x * 64 + wn * 32,
+                                     blockIdx.y, lane);
+}
+
+
+template <int WM>
+static int launch_dma(const GemmArgs& a, const Plan& pl, int epi, hipStream_t st) {
+    dim3 grid(pl.n_tiles, pl.splits, pl.m_tiles), block(128 * WM);
+    constexpr int kDmaLds = dma_lds_bytes(WM);
+#define LCM_DMA(E)                                                                                               \
+    {                                                                                                            \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_dma<E, WM>),    \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kDmaLds); \
+        LCM_HIP_CHECK(attr);                                                                                     \
+        hipLaunchKernelGGL((k_gemm_dma<E, WM>), grid, block, kDmaLds, st, a);                                    \
+    }
+    switch (epi) {
+        case LCMHIP_EPI_STORE: LCM_DMA(LCMHIP_EPI_STORE); break;
+        case LCMHIP_EPI_STORE_F32: LCM_DMA(LCMHIP_EPI_STORE_F32); break;
+        case LCMHIP_EPI_RELU: LCM_DMA(LCMHIP_EPI_RELU); break;
+        case LCMHIP_EPI_SWIGLU: LCM_DMA(LCMHIP_EPI_SWIGLU); break;
+        case LCMHIP_EPI_RESID: LCM_DMA(LCMHIP_EPI_RESID); break;
+        case EPI_PARTIAL: LCM_DMA(EPI_PARTIAL); break;
+        default: return fail(LCMHIP_ERR_INVALID, "gemm: unknown epilogue");
+    }
+#undef LCM_DMA
+    LCM_HIP_CHECK(hipGetLastError());
+    return LCMHIP_OK;
 }
 
 template <typename T, int WM, int WN, int TN>
@@ -290,8 +437,12 @@ static int launch_cfg(const GemmArgs& a, const Plan& pl, int epi, hipStream_t st
 template <typename T>
 static int launch_plan(const GemmArgs& a, const Plan& pl, int epi, hipStream_t st) {
     if (pl.wm == 1) return launch_cfg<T, 1, 4, 4>(a, pl, epi, st);
-    if (pl.wm == 4 && pl.wn == 2) return launch_cfg<T, 4, 2, 2>(a, pl, epi, st);
+    if (pl.wm == 4 && pl.wn == 2) {
+        if (std::is_same<T, bf16_t>::value && dma_mode() != 0) return launch_dma<4>(a, pl, epi, st);
+        return launch_cfg<T, 4, 2, 2>(a, pl, epi, st);
+    }
     if (pl.tn == 4) return launch_cfg<T, 2, 2, 4>(a, pl, epi, st);
+    if (std::is_same<T, bf16_t>::value && dma_mode() >= 2) return launch_dma<2>(a, pl, epi, st);
     return launch_cfg<T, 2, 2, 2>(a, pl, epi, st);
 }
 
