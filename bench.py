@@ -104,7 +104,7 @@ def roofline_pass(model, gen_cls, opt_cls, batch, prompt_len, gen_len, device):
 
 
 # kernel family -> the epilogue id in the HIP symbol rocprofv3 reports for it
-_PMC_SYMBOL = {"den.ffn_in": ", 3>(", "den.norm_mod": "k_norm_modulate", "den.cross_attn": "k_attention"}
+_PMC_SYMBOL = {"den.ffn_in": "k_gemm_dma<3, 4,", "den.norm_mod": "k_norm_modulate", "den.cross_attn": "k_attention"}
 
 
 def pmc_traffic(family):

@@ -294,7 +294,8 @@ typedef const __attribute__((address_space(1))) void* dma_gptr_t;
 typedef __attribute__((address_space(3))) void* dma_lptr_t;
 
 // WM wave rows: (32 WM) activation rows x 64 weight rows per workgroup of 2 WM waves.
-template <int EPI, int WM>
+// NT: non-temporal weight DMA (a single row tile reads every weight row exactly once).
+template <int EPI, int WM, bool NT>
 __global__ __launch_bounds__(128 * WM) void k_gemm_dma(GemmArgs p) {
     constexpr bool DUAL = (EPI == LCMHIP_EPI_SWIGLU);
     constexpr int NW = 2 * WM;                       // waves
@@ -343,8 +344,13 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_dma(GemmArgs p) {
         char* dst = smem + buf * kDmaStage + wid * 1024;
         const uint32_t koff = (uint32_t)c * kDmaChunk;
 #pragma unroll
-        for (int j = 0; j < NG; ++j)
+        for (int j = 0; j < XJ; ++j)
             __builtin_amdgcn_global_load_lds((dma_gptr_t)(src[j] + koff), (dma_lptr_t)(dst + j * NW * 1024), 16, 0, 0);
+#pragma unroll
+        for (int j = XJ; j < NG; ++j) {
+            if constexpr (NT) __builtin_amdgcn_global_load_lds((dma_gptr_t)(src[j] + koff), (dma_lptr_t)(dst + j * NW * 1024), 16, 0, 2);
+            else __builtin_amdgcn_global_load_lds((dma_gptr_t)(src[j] + koff), (dma_lptr_t)(dst + j * NW * 1024), 16, 0, 0);
+        }
     };
 
     f32x4 acc[2][2];
@@ -397,13 +403,18 @@ template <int WM>
 static int launch_dma(const GemmArgs& a, const Plan& pl, int epi, hipStream_t st) {
     dim3 grid(pl.n_tiles, pl.splits, pl.m_tiles), block(128 * WM);
     constexpr int kDmaLds = dma_lds_bytes(WM);
-#define LCM_DMA(E)                                                                                               \
-    {                                                                                                            \
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_dma<E, WM>),    \
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kDmaLds); \
-        LCM_HIP_CHECK(attr);                                                                                     \
-        hipLaunchKernelGGL((k_gemm_dma<E, WM>), grid, block, kDmaLds, st, a);                                    \
+    // Non-temporal weight DMA when a single row tile reads every weight row once (the weights of a model do not
+    // fit the caches between launches): +1 % end to end.  LCMHIP_GEMM_NT=0 switches it off.
+    static const int nt_mode = [] { const char* e = getenv("LCMHIP_GEMM_NT"); return e ? atoi(e) : 1; }();
+    const bool nt = nt_mode != 0 && pl.m_tiles == 1;
+#define LCM_DMA1(E, N)                                                                                              \
+    {                                                                                                               \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_dma<E, WM, N>),    \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kDmaLds);    \
+        LCM_HIP_CHECK(attr);                                                                                        \
+        hipLaunchKernelGGL((k_gemm_dma<E, WM, N>), grid, block, kDmaLds, st, a);                                    \
     }
+#define LCM_DMA(E) { if (nt) LCM_DMA1(E, true) else LCM_DMA1(E, false) }
     switch (epi) {
         case LCMHIP_EPI_STORE: LCM_DMA(LCMHIP_EPI_STORE); break;
         case LCMHIP_EPI_STORE_F32: LCM_DMA(LCMHIP_EPI_STORE_F32); break;
@@ -414,6 +425,7 @@ static int launch_dma(const GemmArgs& a, const Plan& pl, int epi, hipStream_t st
         default: return fail(LCMHIP_ERR_INVALID, "gemm: unknown epilogue");
     }
 #undef LCM_DMA
+#undef LCM_DMA1
     LCM_HIP_CHECK(hipGetLastError());
     return LCMHIP_OK;
 }
