@@ -114,11 +114,22 @@ def pmc_traffic(family):
     key = _PMC_SYMBOL.get(family)
     if key is None or not os.path.exists(path):
         return {"traffic": None}
+    out = {"traffic": None}
     for row in json.load(open(path))["kernels"]:
         if key in row["kernel"]:
-            return {"traffic": row["hbm_bytes_per_launch_corrected"],
-                    "traffic_source": "profiles/r1_pmc_hbm_traffic.json (separate rocprofv3 --pmc passes)"}
-    return {"traffic": None}
+            out = {"traffic": row["hbm_bytes_per_launch_corrected"],
+                   "traffic_source": "profiles/r1_pmc_hbm_traffic.json (separate rocprofv3 --pmc passes)"}
+            break
+    # cross-reference: the same kernel's average duration in the committed rocprofv3 --kernel-trace --stats summary
+    # (pure kernel time; the event pair used above also spans the launch boundary, about 2 us)
+    stats = os.path.join(os.path.dirname(path), "r1_bench_kernel_stats.csv")
+    if os.path.exists(stats):
+        import csv
+        for r in csv.DictReader(open(stats, newline="")):
+            if key in r["Name"]:
+                out["rocprof_avg_us"] = round(float(r["AverageNs"]) / 1e3, 3)
+                break
+    return out
 
 
 def cpu_baseline(batch, prompt_len, sentence_steps):
