@@ -1,16 +1,20 @@
 // C = A * W^T for the row counts of sentence-level generation (M = 1 .. a few hundred rows): the
 // weights are streamed once from HBM and the job is to keep every CU's memory queue full.
 //
-// Decomposition: grid = (weight-row tiles, K splits, row tiles).  A workgroup (4 waves) owns a
-// (32*WM rows) x (64*WN weight rows) tile and a contiguous range of 512-byte K chunks.  A whole
-// chunk of both operands -- 24..36 16-byte loads per lane, all issued back to back -- is pulled
-// into registers, written to LDS in full 512-byte rows (+16 B pad: conflict-free 16-byte
-// fragment reads) and consumed by the matrix cores while the next chunk's loads are in flight.
-// With split-K the fp32 partial tiles go to a slab [split][row][col]; they are summed by the
-// consumer (the fused residual+norm kernel, or k_splitk_finish) -- no atomics, deterministic.
+// Decomposition: grid = (weight-row tiles, K splits, row tiles).  With split-K the fp32 partial tiles go to a slab
+// [split][row][col]; they are summed by the consumer (the fused residual+norm kernel, the attention kernel, or
+// k_splitk_finish) -- no atomics, deterministic.
 // MFMA orientation: WEIGHT rows are the matrix-core A operand, ACTIVATION rows the B operand, so
 // a lane holds 4 consecutive output columns of one row (vector bias/gate loads, vector stores).
 //   bf16 operands: v_mfma_f32_16x16x32_bf16;  f32 operands: v_mfma_f32_16x16x4_f32 (exact fp32).
+// Two kernels:
+//   k_gemm_dma  bf16, row tiles of 64 or 128 rows (the shapes of the sampling loop): operands staged global -> LDS by
+//               LDS-DMA, three stages, see its own comment;
+//   k_gemm      everything else (fp32; bf16 with at most 32 rows or very wide 64-row problems): a workgroup owns a
+//               (32*WM rows) x (16*TN*WN weight rows) tile and a range of 512-byte K chunks; a whole chunk of both
+//               operands -- 24..36 16-byte loads per lane, all issued back to back -- is pulled into registers,
+//               written to LDS in full 512-byte rows (+16 B pad: conflict-free 16-byte fragment reads) and consumed
+//               by the matrix cores while the next chunk's loads are in flight.
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
