@@ -227,12 +227,25 @@ struct DdimScalars {
     int prediction_type;
     int mode;                        // 0: plain step on out_cond with prediction_type; 1: CFG (eps space)
 };
+// Optional inputs / outputs of the fused step: the model output still sitting in the split-K slab of the final
+// projection ([splits][rows_total][dim]; conditional rows first, unconditional rows `rows` further down) with its
+// bias, and a copy of prev_sample in the operand dtype for the next step's initial projection.
+struct DdimIO {
+    const float* partial = nullptr;
+    int splits = 0;
+    int rows_total = 0;
+    const void* bias = nullptr;
+    void* prev_cast = nullptr;
+    int bf16 = 0;                    // dtype of bias and prev_cast
+};
 int launch_ddim_step(const float* sample, const float* out_c, const float* out_u, float* prev, float* x0, int rows,
-                     int dim, const DdimScalars& sc, hipStream_t st);
+                     int dim, const DdimScalars& sc, hipStream_t st, const DdimIO* io = nullptr);
 // Final: y = x0 * scale + center (T-typed center/scale) -> fp32
 int launch_denormalize_f32_out(const float* x0, const void* center, const void* scale, float* y, int64_t rows,
                                int dim, int dtype, hipStream_t st);
-int launch_init_latents(const float* noise, float* lat, int64_t n, float sigma, float clip, hipStream_t st);
+// cast != nullptr: also a copy of the latents in `dtype` (the first step's initial projection reads it)
+int launch_init_latents(const float* noise, float* lat, int64_t n, float sigma, float clip, hipStream_t st,
+                        void* cast = nullptr, int dtype = LCMHIP_F32);
 // q/k/v (rows, d) T: rotate q in place, write rotated k and v into the cache rows given by cache_rows.
 int launch_rope_store(void* q, const void* k, const void* v, void* kc, void* vc, const int32_t* cache_rows,
                       const int32_t* positions, const float* cos_tab, const float* sin_tab, int rows, int d,

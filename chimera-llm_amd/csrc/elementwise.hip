@@ -421,11 +421,32 @@ __device__ __forceinline__ float eps_from_output(float out, float x, const DdimS
 
 __global__ __launch_bounds__(256) void k_ddim_step(const float* __restrict__ sample, const float* __restrict__ out_c,
                                                    const float* __restrict__ out_u, float* __restrict__ prev,
-                                                   float* __restrict__ x0_out, int dim, DdimScalars sc) {
+                                                   float* __restrict__ x0_out, int dim, DdimScalars sc, DdimIO io) {
     constexpr int MAXV = 4;
     __shared__ float red[4];
     const size_t base = (size_t)blockIdx.x * dim;
     const int nv = dim / 4;
+    // model output of row `r` (conditional rows first, then the unconditional ones): a finished tensor, or the sum of
+    // the split-K slabs of the final projection plus its bias (same order as the finishing pass would use)
+    auto model_out = [&](const float* fin, int r, int ch) {
+        if (io.partial == nullptr) return *reinterpret_cast<const float4*>(fin + base + ch * 4);
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int sp = 0; sp < io.splits; ++sp) {
+            const float4 t = *reinterpret_cast<const float4*>(io.partial + ((size_t)sp * io.rows_total + r) * dim + ch * 4);
+            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        }
+        if (io.bias != nullptr) {
+            if (io.bf16) {
+                const bf16_t* bp = reinterpret_cast<const bf16_t*>(io.bias) + ch * 4;
+                a.x += Elem<bf16_t>::load(bp); a.y += Elem<bf16_t>::load(bp + 1); a.z += Elem<bf16_t>::load(bp + 2); a.w += Elem<bf16_t>::load(bp + 3);
+            } else {
+                const float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(io.bias) + ch * 4);
+                a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+            }
+        }
+        return a;
+    };
+    const int row_c = blockIdx.x, row_u = blockIdx.x + gridDim.x;
     float x[MAXV][4], e[MAXV][4], x0[MAXV][4];
     if (sc.mode == 1) {
         // guidance in epsilon space
@@ -436,8 +457,8 @@ __global__ __launch_bounds__(256) void k_ddim_step(const float* __restrict__ sam
             const int ch = threadIdx.x + i * 256;
             if (ch < nv) {
                 const float4 xv = *reinterpret_cast<const float4*>(sample + base + ch * 4);
-                const float4 cv = *reinterpret_cast<const float4*>(out_c + base + ch * 4);
-                const float4 uv = *reinterpret_cast<const float4*>(out_u + base + ch * 4);
+                const float4 cv = model_out(out_c, row_c, ch);
+                const float4 uv = model_out(out_u, row_u, ch);
                 const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, cs[4] = {cv.x, cv.y, cv.z, cv.w},
                             us[4] = {uv.x, uv.y, uv.z, uv.w};
 #pragma unroll
@@ -484,7 +505,7 @@ __global__ __launch_bounds__(256) void k_ddim_step(const float* __restrict__ sam
             const int ch = threadIdx.x + i * 256;
             if (ch < nv) {
                 const float4 xv = *reinterpret_cast<const float4*>(sample + base + ch * 4);
-                const float4 cv = *reinterpret_cast<const float4*>(out_c + base + ch * 4);
+                const float4 cv = model_out(out_c, row_c, ch);
                 const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, cs[4] = {cv.x, cv.y, cv.z, cv.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -519,16 +540,32 @@ __global__ __launch_bounds__(256) void k_ddim_step(const float* __restrict__ sam
             }
             *reinterpret_cast<float4*>(prev + base + ch * 4) = make_float4(p[0], p[1], p[2], p[3]);
             *reinterpret_cast<float4*>(x0_out + base + ch * 4) = make_float4(z[0], z[1], z[2], z[3]);
+            if (io.prev_cast != nullptr) {   // the next step's initial projection reads the latents in the operand dtype
+                if (io.bf16) {
+                    uint2 pk;
+                    pk.x = (uint32_t)f32_to_bf16(p[0]) | ((uint32_t)f32_to_bf16(p[1]) << 16);
+                    pk.y = (uint32_t)f32_to_bf16(p[2]) | ((uint32_t)f32_to_bf16(p[3]) << 16);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(io.prev_cast) + base + ch * 4) = pk;
+                } else {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(io.prev_cast) + base + ch * 4) = make_float4(p[0], p[1], p[2], p[3]);
+                }
+            }
         }
     }
 }
 
 int launch_ddim_step(const float* sample, const float* out_c, const float* out_u, float* prev, float* x0, int rows,
-                     int dim, const DdimScalars& sc, hipStream_t st) {
+                     int dim, const DdimScalars& sc, hipStream_t st, const DdimIO* io_in) {
     LCM_REQUIRE(dim % 4 == 0 && dim <= 4096 && dim > 1, "ddim: dim must be a multiple of 4 and <= 4096");
-    LCM_REQUIRE(sc.mode == 0 || out_u != nullptr, "ddim: guidance needs the unconditional output");
+    DdimIO io;
+    if (io_in) io = *io_in;
+    if (io.partial != nullptr) {
+        LCM_REQUIRE(io.splits >= 1 && io.rows_total >= (sc.mode == 1 ? 2 * rows : rows), "ddim: bad split-K model output");
+    } else {
+        LCM_REQUIRE(out_c != nullptr && (sc.mode == 0 || out_u != nullptr), "ddim: guidance needs the unconditional output");
+    }
     if (rows <= 0) return LCMHIP_OK;
-    hipLaunchKernelGGL(k_ddim_step, dim3(rows), dim3(256), 0, st, sample, out_c, out_u, prev, x0, dim, sc);
+    hipLaunchKernelGGL(k_ddim_step, dim3(rows), dim3(256), 0, st, sample, out_c, out_u, prev, x0, dim, sc, io);
     LCM_HIP_CHECK(hipGetLastError());
     return LCMHIP_OK;
 }
@@ -537,7 +574,7 @@ int launch_ddim_step(const float* sample, const float* out_c, const float* out_u
 // small helpers
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_init_latents(const float* __restrict__ noise, float* __restrict__ lat,
-                                                      int64_t n4, float sigma, float clip) {
+                                                      int64_t n4, float sigma, float clip, void* cast, int bf16) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         float4 v = reinterpret_cast<const float4*>(noise)[i];
         v.x = fminf(fmaxf(v.x * sigma, -clip), clip);
@@ -545,13 +582,25 @@ __global__ __launch_bounds__(256) void k_init_latents(const float* __restrict__ 
         v.z = fminf(fmaxf(v.z * sigma, -clip), clip);
         v.w = fminf(fmaxf(v.w * sigma, -clip), clip);
         reinterpret_cast<float4*>(lat)[i] = v;
+        if (cast != nullptr) {
+            if (bf16) {
+                uint2 pk;
+                pk.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+                pk.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+                reinterpret_cast<uint2*>(cast)[i] = pk;
+            } else {
+                reinterpret_cast<float4*>(cast)[i] = v;
+            }
+        }
     }
 }
 
-int launch_init_latents(const float* noise, float* lat, int64_t n, float sigma, float clip, hipStream_t st) {
+int launch_init_latents(const float* noise, float* lat, int64_t n, float sigma, float clip, hipStream_t st, void* cast,
+                        int dtype) {
     LCM_REQUIRE(n % 4 == 0, "latents: size must be a multiple of 4");
     if (n == 0) return LCMHIP_OK;
-    hipLaunchKernelGGL(k_init_latents, dim3(grid_for(n / 4, 256)), dim3(256), 0, st, noise, lat, n / 4, sigma, clip);
+    hipLaunchKernelGGL(k_init_latents, dim3(grid_for(n / 4, 256)), dim3(256), 0, st, noise, lat, n / 4, sigma, clip, cast,
+                       dtype == LCMHIP_BF16 ? 1 : 0);
     LCM_HIP_CHECK(hipGetLastError());
     return LCMHIP_OK;
 }

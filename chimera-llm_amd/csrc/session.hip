@@ -193,7 +193,7 @@ struct lcmhip_session {
     float *mod_table = nullptr, *uconst = nullptr;
     float *xres = nullptr, *outp = nullptr, *lat = nullptr, *lat2 = nullptr, *x0 = nullptr, *f32tmp = nullptr;
     char *act_a = nullptr, *act_q = nullptr, *act_k = nullptr, *act_v = nullptr, *act_o = nullptr, *act_h = nullptr,
-         *act_in = nullptr;
+         *act_in = nullptr, *act_lat = nullptr;
     float* kept_ctx = nullptr;
     float *slab_p = nullptr, *slab_q = nullptr;   // split-K slabs: pending products / internal finishing
     int32_t* d_cross_keys = nullptr;              // device copy of ctx_len + 1 (read by graph-recorded attention launches)
@@ -262,6 +262,7 @@ static size_t carve(lcmhip_session* s, char* base) {
     s->lat2 = c.take<float>(B * D * 4);
     s->x0 = c.take<float>(B * D * 4);
     s->act_in = c.take<char>(R * std::max(D, (size_t)d.timestep_freq_dim) * es);
+    s->act_lat = c.take<char>(B * D * es);
     s->act_a = c.take<char>(R * dm * es);
     s->act_q = c.take<char>(R * dm * es);
     s->act_k = c.take<char>(R * dm * es);
@@ -914,7 +915,8 @@ static int denoise_body(lcmhip_session* s, const float* noise, float* out, float
     const size_t cross_layer = (size_t)s->max_batch * (s->cap + 1) * dm * es;
     const int nkeys = s->ctx_len + 1;
 
-    LCM_TRY(launch_init_latents(noise, s->lat, (int64_t)B * D, s->params.init_noise_sigma, s->params.clip_noise, st));
+    // the latents also live in the operand dtype (act_lat), written by the kernels that produce them
+    LCM_TRY(launch_init_latents(noise, s->lat, (int64_t)B * D, s->params.init_noise_sigma, s->params.clip_noise, st, s->act_lat, d.dtype));
     float* lat = s->lat;
     float* lat_next = s->lat2;
     for (int si = 0; si < s->n_steps; ++si) {
@@ -923,9 +925,8 @@ static int denoise_body(lcmhip_session* s, const float* noise, float* out, float
         const float* mod_step = s->mod_table + (size_t)si * L * 9 * dm;
         // initial projection: both halves of the doubled batch see the same latents; the product stays
         // in the split-K slab and the first norm kernel writes it (duplicated) into the residual stream
-        LCM_TRY(launch_cast(lat, s->act_in, (int64_t)B * D, d.dtype, st));
         Pending pend;
-        LCM_TRY(gemm_pending(s, "den.initial_proj", s->act_in, D, m->init_proj, nullptr, B, &pend, st));
+        LCM_TRY(gemm_pending(s, "den.initial_proj", s->act_lat, D, m->init_proj, nullptr, B, &pend, st));
         pend.init = 1;
         pend.dup = 1;
         for (int l = 0; l < L; ++l) {
@@ -959,10 +960,15 @@ static int denoise_body(lcmhip_session* s, const float* noise, float* out, float
             LCM_TRY(gemm_pending(s, "den.ffn_out", s->act_h, td.ffn_dim, Ly.ffn.out, mod + 8 * dm, rows, &pend, st));
         }
         LCM_TRY(norm(s, "den.norm_mod", s->xres, m->den_final, nullptr, nullptr, s->act_a, rows, rows, td.norm_kind, &pend, st));
-        LCM_TRY(gemm(s, "den.final_proj", s->act_a, dm, m->final_proj, nullptr, nullptr, s->outp, D, rows, LCMHIP_EPI_STORE_F32, st));
+        // the final projection stays in its split-K slab: the fused DDIM / guidance step sums it
+        Pending fp;
+        LCM_TRY(gemm_pending(s, "den.final_proj", s->act_a, dm, m->final_proj, nullptr, rows, &fp, st, s->slab_q));
         {
-            ProfScope ps(&s->prof, "den.ddim_cfg_step", (double)B * D * 4.0 * (rows == 2 * B ? 5.0 : 4.0), 0.0, st);
-            LCM_TRY(launch_ddim_step(lat, s->outp, rows == 2 * B ? s->outp + (size_t)B * D : nullptr, lat_next, s->x0, B, D, sc, st));
+            DdimIO io;
+            io.partial = fp.partial; io.splits = fp.splits; io.rows_total = rows; io.bias = fp.bias;
+            io.prev_cast = s->act_lat; io.bf16 = d.dtype == LCMHIP_BF16 ? 1 : 0;
+            ProfScope ps(&s->prof, "den.ddim_cfg_step", (double)B * D * 4.0 * (3.0 + fp.splits * (rows == 2 * B ? 2.0 : 1.0)), 0.0, st);
+            LCM_TRY(launch_ddim_step(lat, nullptr, nullptr, lat_next, s->x0, B, D, sc, st, &io));
         }
         std::swap(lat, lat_next);
         if (latents_trace)
