@@ -31,4 +31,4 @@ with torch.cuda.stream(st):
         cold = run(caches, keys, 260)
         hot = run(caches[:1], keys, 260)
         mb = 2 * B * H * keys * 256 / 1e6
-        print(f"keys {keys:4d}  {mb:6.1f} MB   cold {cold:6.2f} us ({mb / cold / 1e6 * 1e6 / 1e6:.2f} TB/s)   hot {hot:6.2f} us", flush=True)
+        print(f"keys {keys:4d}  {mb:6.1f} MB   cold {cold:6.2f} us ({mb / cold:.2f} TB/s)   hot {hot:6.2f} us", flush=True)
