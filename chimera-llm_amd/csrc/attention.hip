@@ -56,6 +56,36 @@ __device__ __forceinline__ void unpack8<float>(const Piece<float>& r, float (&v)
     for (int j = 0; j < 8; ++j) v[j] = r[j];
 }
 
+// Sum of v[0..31] over the 16 key slots of a wave (lane bits 2..5) as a reduce-scatter: every round exchanges the half
+// of the values this lane does NOT keep (30 shuffles instead of 128 for a butterfly over all 32 values).  Afterwards
+// v[x], x < 2, holds the complete sum of original index 2 * (lane / 4) + x.
+__device__ __forceinline__ void slot_reduce_scatter(float (&v)[32], int lane) {
+#pragma unroll
+    for (int half = 16, off = 32; half >= 2; half >>= 1, off >>= 1) {
+        const bool up = (lane & off) != 0;
+#pragma unroll
+        for (int j = 0; j < half; ++j) {
+            const float lo = v[j], hi = v[j + half];
+            const float recv = __shfl_xor(up ? lo : hi, off, 64);
+            v[j] = (up ? hi : lo) + recv;
+        }
+    }
+}
+// The inverse exchange: v[x], x < 2, of every slot -> all 32 values in every slot.
+__device__ __forceinline__ void slot_all_gather(float (&v)[32], int lane) {
+#pragma unroll
+    for (int n = 2, off = 4; n <= 16; n <<= 1, off <<= 1) {
+        const bool up = (lane & off) != 0;
+#pragma unroll
+        for (int j = 0; j < n; ++j) {
+            const float a = v[j];
+            const float r = __shfl_xor(a, off, 64);
+            v[j] = up ? r : a;
+            v[j + n] = up ? a : r;
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_attention(AttnQ qa, const T* __restrict__ kc, const T* __restrict__ vc,
                                                    const int32_t* __restrict__ slot_map, T* __restrict__ out, int s,
@@ -81,8 +111,8 @@ __global__ __launch_bounds__(256) void k_attention(AttnQ qa, const T* __restrict
     float qv[4][8];
     if (qa.partial != nullptr) {
         // split-K slab of the q projection: key slot ks sums splits ks, ks + 16, ... for this lane's 32 dims
-        // (one round of loads for up to 16 splits), then the 16 slots are added with a butterfly, which
-        // leaves the same bits in every slot.
+        // (one round of loads for up to 16 splits), then the 16 slots are added (reduce-scatter + all-gather),
+        // which leaves the same bits in every slot.
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -106,12 +136,19 @@ __global__ __launch_bounds__(256) void k_attention(AttnQ qa, const T* __restrict
                 for (int t = 0; t < 8; ++t) qv[i][t] += b8[t];
             }
         }
-#pragma unroll
-        for (int off = 4; off <= 32; off <<= 1)
+        {
+            float flat[32];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int t = 0; t < 8; ++t) qv[i][t] += __shfl_xor(qv[i][t], off, 64);
+                for (int t = 0; t < 8; ++t) flat[8 * i + t] = qv[i][t];
+            slot_reduce_scatter(flat, lane);
+            slot_all_gather(flat, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) qv[i][t] = flat[8 * i + t];
+        }
         // the reference rounds q to the operand dtype before the scores
         if (sizeof(T) == 2) {
 #pragma unroll
@@ -198,32 +235,28 @@ __global__ __launch_bounds__(256) void k_attention(AttnQ qa, const T* __restrict
         const float s0 = score(kp);
         absorb(s0, vp);
     }
-    // merge the 16 key slots (lane bits 2..5)
+    // merge the 16 key slots (lane bits 2..5): common maximum, rescale once, then sums
+    float M = m;
 #pragma unroll
-    for (int off = 4; off <= 32; off <<= 1) {
-        const float mo = __shfl_xor(m, off, 64);
-        const float lo = __shfl_xor(l, off, 64);
-        const float mn = fmaxf(m, mo);
-        const float a = (m == -INFINITY) ? 0.f : __expf(m - mn);
-        const float b = (mo == -INFINITY) ? 0.f : __expf(mo - mn);
-        l = l * a + lo * b;
+    for (int off = 4; off <= 32; off <<= 1) M = fmaxf(M, __shfl_xor(M, off, 64));
+    const float f = (m == -INFINITY) ? 0.f : __expf(m - M);      // slot 0 always holds key 0: M is finite
+    float lsum = l * f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+    for (int off = 4; off <= 32; off <<= 1) lsum += __shfl_xor(lsum, off, 64);
+    float flat[32];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const float ao = __shfl_xor(acc[i][t], off, 64);
-                acc[i][t] = acc[i][t] * a + ao * b;
-            }
-        m = mn;
-    }
-    if (ks == 0) {
-        const float inv = 1.f / l;
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float o[8];
-#pragma unroll
-            for (int t = 0; t < 8; ++t) o[t] = acc[i][t] * inv;
-            store8<T>(out + (size_t)row * d + col + 32 * i, o);
+        for (int t = 0; t < 8; ++t) flat[8 * i + t] = acc[i][t] * f;
+    slot_reduce_scatter(flat, lane);
+    // this lane now holds flat index 2 ks + x = piece (ks / 4), element 2 (ks % 4) + x of its dim group
+    {
+        const float inv = 1.f / lsum;
+        T* dst = out + (size_t)row * d + col + 32 * (ks >> 2) + 2 * (ks & 3);
+        if (sizeof(T) == 4) {
+            *reinterpret_cast<float2*>(dst) = make_float2(flat[0] * inv, flat[1] * inv);
+        } else {
+            *reinterpret_cast<uint32_t*>(dst) = (uint32_t)f32_to_bf16(flat[0] * inv) | ((uint32_t)f32_to_bf16(flat[1] * inv) << 16);
         }
     }
 }
