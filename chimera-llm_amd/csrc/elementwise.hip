@@ -268,6 +268,134 @@ __global__ __launch_bounds__(NT) void k_norm_modulate(float* __restrict__ x, con
     }
 }
 
+// The same kernel for the shapes of the sampling loop (a pending split-K product, dim == 4 * NT: one float4 per
+// lane), written without a single data-dependent branch around a load: every operand -- residual, up to MAXS slabs,
+// bias, gate, constant row, norm weight / bias, modulation -- is requested back to back (absent ones are read from a
+// valid dummy address and masked), so the kernel costs ONE memory round trip instead of one per operand group.
+// Splits past pd.splits re-read the last slab (MAXS - splits <= 3 redundant, cache-resident loads).  Same arithmetic,
+// in the same order, as k_norm_modulate.
+template <typename T>
+__device__ __forceinline__ float4 load4(const T* p);
+template <>
+__device__ __forceinline__ float4 load4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <>
+__device__ __forceinline__ float4 load4<bf16_t>(const bf16_t* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+}
+
+template <typename T, int KIND, int NT, int MAXS, bool INIT>
+__global__ __launch_bounds__(NT) void k_norm_pending(float* __restrict__ x, const T* __restrict__ w, const T* __restrict__ b,
+                                                      const float* __restrict__ shift, const float* __restrict__ scale,
+                                                      T* __restrict__ y, int rows_norm, float eps, Pending pd, RowSteps rs) {
+    constexpr int dim = 4 * NT;
+    __shared__ float red[NT / 64];
+    const int row = blockIdx.x, c4 = threadIdx.x * 4;
+    size_t moff = 0;
+    if (rs.row_step != nullptr) moff = (size_t)min(max(rs.row_step[row], 0), rs.n_steps - 1) * rs.step_stride;
+    float* xr = x + (size_t)row * dim + c4;
+    const int src_row = row < pd.M ? row : (pd.dup ? row - pd.M : -1);
+    const bool real = src_row >= 0;                       // uniform per workgroup
+    const int sr = real ? src_row : 0;
+    const float* dummy = pd.partial + c4;                 // valid fp32 memory for absent operands
+    // ---- every load
+    float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);          // INIT: the product starts the residual stream
+    if constexpr (!INIT) xv = *reinterpret_cast<const float4*>(xr);
+    float4 t[MAXS];
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s)
+        t[s] = *reinterpret_cast<const float4*>(pd.partial + ((size_t)min(s, pd.splits - 1) * pd.M + sr) * dim + c4);
+    const float4 bv = load4<T>((pd.bias != nullptr ? reinterpret_cast<const T*>(pd.bias) : w) + c4);
+    const float4 gv = *reinterpret_cast<const float4*>(pd.gate != nullptr ? pd.gate + moff + c4 : dummy);
+    const float4 ev = *reinterpret_cast<const float4*>(pd.extra_const != nullptr ? pd.extra_const + c4 : dummy);
+    const float4 wv = load4<T>(w + c4);
+    const float4 nb = load4<T>((KIND == LCMHIP_NORM_LAYERNORM && b != nullptr ? b : w) + c4);
+    const float4 scv = *reinterpret_cast<const float4*>(scale != nullptr ? scale + moff + c4 : dummy);
+    const float4 shv = *reinterpret_cast<const float4*>(shift != nullptr ? shift + moff + c4 : dummy);
+    // ---- residual update: x = (init ? 0 : x) + gate * (sum of slabs + bias | constant row)
+    // (slabs past the split count are weighted by 0 instead of skipped: a skipped use lets the compiler sink the
+    // load into the branch and wait for it there, one extra round trip)
+    float a[4] = {t[0].x, t[0].y, t[0].z, t[0].w};
+#pragma unroll
+    for (int s = 1; s < MAXS; ++s) {
+        const float on = s < pd.splits ? 1.f : 0.f;
+        a[0] = fmaf(t[s].x, on, a[0]); a[1] = fmaf(t[s].y, on, a[1]); a[2] = fmaf(t[s].z, on, a[2]); a[3] = fmaf(t[s].w, on, a[3]);
+    }
+    {
+        const float on = pd.bias != nullptr ? 1.f : 0.f;
+        a[0] = fmaf(bv.x, on, a[0]); a[1] = fmaf(bv.y, on, a[1]); a[2] = fmaf(bv.z, on, a[2]); a[3] = fmaf(bv.w, on, a[3]);
+    }
+    if (!real) { a[0] = ev.x; a[1] = ev.y; a[2] = ev.z; a[3] = ev.w; }
+    if (pd.gate != nullptr) { a[0] *= gv.x; a[1] *= gv.y; a[2] *= gv.z; a[3] *= gv.w; }
+    float v[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] += a[j];
+    *reinterpret_cast<float4*>(xr) = make_float4(v[0], v[1], v[2], v[3]);
+    if (row >= rows_norm) return;   // uniform per workgroup
+    // ---- statistics
+    float mean = 0.f, rstd;
+    if (KIND == LCMHIP_NORM_RMS) {
+        const float ss = block_sum<NT / 64>(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3], red);
+        rstd = rsqrtf(ss / dim + eps);
+    } else {
+        mean = block_sum<NT / 64>(v[0] + v[1] + v[2] + v[3], red) / dim;
+        const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+        const float q = block_sum<NT / 64>(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3, red);
+        rstd = rsqrtf(q / dim + eps);
+    }
+    const float pw[4] = {wv.x, wv.y, wv.z, wv.w};
+    const float pb[4] = {nb.x, nb.y, nb.z, nb.w};
+    const float psc[4] = {scv.x, scv.y, scv.z, scv.w}, psh[4] = {shv.x, shv.y, shv.z, shv.w};
+    const bool has_b = KIND == LCMHIP_NORM_LAYERNORM && b != nullptr, has_mod = scale != nullptr;
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float tt = (v[j] - mean) * rstd * pw[j] + (has_b ? pb[j] : 0.f);
+        o[j] = tt * (1.f + (has_mod ? psc[j] : 0.f)) + (has_mod ? psh[j] : 0.f);
+    }
+    T* yr = y + (size_t)row * dim + c4;
+    if (sizeof(T) == 4) {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(yr)) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+        uint2 pk;
+        pk.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
+        pk.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(yr)) = pk;
+    }
+}
+
+template <typename T, int KIND, int NT>
+static void launch_norm_pending(float* x, const void* w, const void* b, const float* shift, const float* scale, void* y,
+                                int rows, int rows_norm, float eps, const Pending& pd, const RowSteps& rs, hipStream_t st) {
+#define LCM_NP(MAXS)                                                                                                   \
+    {                                                                                                                  \
+        if (pd.init)                                                                                                   \
+            hipLaunchKernelGGL((k_norm_pending<T, KIND, NT, MAXS, true>), dim3(rows), dim3(NT), 0, st, x, (const T*)w, \
+                               (const T*)b, shift, scale, (T*)y, rows_norm, eps, pd, rs);                              \
+        else                                                                                                           \
+            hipLaunchKernelGGL((k_norm_pending<T, KIND, NT, MAXS, false>), dim3(rows), dim3(NT), 0, st, x, (const T*)w, \
+                               (const T*)b, shift, scale, (T*)y, rows_norm, eps, pd, rs);                              \
+    }
+    if (pd.splits == 1) LCM_NP(1)
+    else if (pd.splits <= 4) LCM_NP(4)
+    else if (pd.splits <= 8) LCM_NP(8)
+    else LCM_NP(12)
+#undef LCM_NP
+}
+
+template <typename T, int KIND>
+static bool try_norm_pending(float* x, const void* w, const void* b, const float* shift, const float* scale, void* y,
+                             int rows, int rows_norm, int dim, float eps, const Pending& pd, const RowSteps& rs, hipStream_t st) {
+    if (pd.splits > 12) return false;
+    switch (dim) {
+        case 1024: launch_norm_pending<T, KIND, 256>(x, w, b, shift, scale, y, rows, rows_norm, eps, pd, rs, st); return true;
+        case 2048: launch_norm_pending<T, KIND, 512>(x, w, b, shift, scale, y, rows, rows_norm, eps, pd, rs, st); return true;
+        case 4096: launch_norm_pending<T, KIND, 1024>(x, w, b, shift, scale, y, rows, rows_norm, eps, pd, rs, st); return true;
+        default: return false;
+    }
+}
+
 // Many rows, nothing pending: one wave per row (4 rows per workgroup), the row in registers, statistics by wave
 // shuffles only -- no LDS, no barrier.  dim <= 4096, dim % 256 == 0.
 template <typename T, int KIND, int NV>
@@ -385,6 +513,20 @@ int launch_norm_modulate(float* x, const void* w, const void* b, const float* sh
         else if (dtype == LCMHIP_F32)
             done = norm_kind == LCMHIP_NORM_RMS ? launch_norm_rows<float, LCMHIP_NORM_RMS>(x, w, b, shift, scale, y, rows, dim, eps, st, rs)
                                                 : launch_norm_rows<float, LCMHIP_NORM_LAYERNORM>(x, w, b, shift, scale, y, rows, dim, eps, st, rs);
+        if (done) {
+            LCM_HIP_CHECK(hipGetLastError());
+            return LCMHIP_OK;
+        }
+    }
+    if (pend) {
+        static const int fast = [] { const char* e = getenv("LCMHIP_NORM_FAST"); return e ? atoi(e) : 1; }();
+        bool done = false;
+        if (fast && dtype == LCMHIP_BF16)
+            done = norm_kind == LCMHIP_NORM_RMS ? try_norm_pending<bf16_t, LCMHIP_NORM_RMS>(x, w, b, shift, scale, y, rows, rows_norm, dim, eps, pd, rs, st)
+                                                : try_norm_pending<bf16_t, LCMHIP_NORM_LAYERNORM>(x, w, b, shift, scale, y, rows, rows_norm, dim, eps, pd, rs, st);
+        else if (fast && dtype == LCMHIP_F32)
+            done = norm_kind == LCMHIP_NORM_RMS ? try_norm_pending<float, LCMHIP_NORM_RMS>(x, w, b, shift, scale, y, rows, rows_norm, dim, eps, pd, rs, st)
+                                                : try_norm_pending<float, LCMHIP_NORM_LAYERNORM>(x, w, b, shift, scale, y, rows, rows_norm, dim, eps, pd, rs, st);
         if (done) {
             LCM_HIP_CHECK(hipGetLastError());
             return LCMHIP_OK;
