@@ -113,6 +113,13 @@ __global__ __launch_bounds__(256) void k_attention(AttnQ qa, const T* __restrict
         // split-K slab of the q projection: key slot ks sums splits ks, ks + 16, ... for this lane's 32 dims
         // (one round of loads for up to 16 splits), then the 16 slots are added (reduce-scatter + all-gather),
         // which leaves the same bits in every slot.
+        // bias first and for every lane (slot 0 alone adds it): requested in the same round trip as the slab, not
+        // in a second, dependent one for four lanes
+        float b8[4][8];
+        const bool has_bias = qa.bias != nullptr;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            load8<T>(reinterpret_cast<const T*>(has_bias ? qa.bias : (const void*)kc) + col + 32 * i, b8[i]);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -127,14 +134,12 @@ __global__ __launch_bounds__(256) void k_attention(AttnQ qa, const T* __restrict
                 for (int t = 0; t < 8; ++t) qv[i][t] += t8[t];
             }
         }
-        if (qa.bias != nullptr && ks == 0) {
+        {
+            const float on = (has_bias && ks == 0) ? 1.f : 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float b8[8];
-                load8<T>(reinterpret_cast<const T*>(qa.bias) + col + 32 * i, b8);
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int t = 0; t < 8; ++t) qv[i][t] += b8[t];
-            }
+                for (int t = 0; t < 8; ++t) qv[i][t] = fmaf(b8[i][t], on, qv[i][t]);
         }
         {
             float flat[32];
