@@ -326,7 +326,11 @@ __global__ __launch_bounds__(NT) void k_norm_pending(float* __restrict__ x, cons
         const float on = pd.bias != nullptr ? 1.f : 0.f;
         a[0] = fmaf(bv.x, on, a[0]); a[1] = fmaf(bv.y, on, a[1]); a[2] = fmaf(bv.z, on, a[2]); a[3] = fmaf(bv.w, on, a[3]);
     }
-    if (!real) { a[0] = ev.x; a[1] = ev.y; a[2] = ev.z; a[3] = ev.w; }
+    {   // rows past the product take the constant row instead (a blend, not a branch: see above)
+        const float keep = real ? 1.f : 0.f, take = real ? 0.f : 1.f;
+        a[0] = fmaf(ev.x, take, a[0] * keep); a[1] = fmaf(ev.y, take, a[1] * keep);
+        a[2] = fmaf(ev.z, take, a[2] * keep); a[3] = fmaf(ev.w, take, a[3] * keep);
+    }
     if (pd.gate != nullptr) { a[0] *= gv.x; a[1] *= gv.y; a[2] *= gv.z; a[3] *= gv.w; }
     float v[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
