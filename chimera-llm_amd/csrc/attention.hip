@@ -108,15 +108,18 @@ __global__ __launch_bounds__(256) void k_attention(AttnQ qa, const T* __restrict
     const int ks = lane >> 2, dg = lane & 3;
     const int col = head * kHeadDim + dg * 8;           // piece i of this lane starts at col + 32 * i
 
-    float qv[4][8];
-    if (qa.partial != nullptr) {
-        // split-K slab of the q projection: key slot ks sums splits ks, ks + 16, ... for this lane's 32 dims
-        // (one round of loads for up to 16 splits), then the 16 slots are added (reduce-scatter + all-gather),
-        // which leaves the same bits in every slot.
-        // bias first and for every lane (slot 0 alone adds it): requested in the same round trip as the slab, not
-        // in a second, dependent one for four lanes
-        float b8[4][8];
-        const bool has_bias = qa.bias != nullptr;
+    // Loads are requested in the order their data is needed (the memory counter retires in order): the query's own
+    // operands, then the first round of keys / values, which so stays in flight while the query is assembled.
+    constexpr int U = sizeof(T) == 2 ? 4 : 2;           // keys per slot and round (16 * U keys per wave)
+    const size_t hbase = ((size_t)slot * n_heads + head) * cap * kHeadDim + dg * 8;
+    const T* kbase = kc + hbase;
+    const T* vbase = vc + hbase;
+    float qv[4][8], b8[4][8];
+    const bool from_slab = qa.partial != nullptr;
+    const bool has_bias = from_slab && qa.bias != nullptr;
+    if (from_slab) {
+        // split-K slab of the q projection: key slot ks sums splits ks, ks + 16, ... for this lane's 32 dims (one
+        // round of loads for up to 16 splits); the bias for every lane (slot 0 alone adds it), in the same round trip
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             load8<T>(reinterpret_cast<const T*>(has_bias ? qa.bias : (const void*)kc) + col + 32 * i, b8[i]);
@@ -124,7 +127,29 @@ __global__ __launch_bounds__(256) void k_attention(AttnQ qa, const T* __restrict
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int t = 0; t < 8; ++t) qv[i][t] = 0.f;
-        for (int sp = ks; sp < qa.splits; sp += 16) {
+        if (ks < qa.splits) {
+            const float* src = qa.partial + ((size_t)ks * qa.rows + row) * d + col;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) load8<float>(src + 32 * i, qv[i]);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load8<T>(reinterpret_cast<const T*>(qa.q) + (size_t)row * d + col + 32 * i, qv[i]);
+    }
+    Piece<T> kp0[U][4], vp0[U][4];
+    const bool first_full = ks + 16 * (U - 1) < nkeys;  // this slot takes part in a first full round
+    if (first_full) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) kp0[u][i] = load_piece<T>(kbase + (size_t)(ks + 16 * u) * kHeadDim + 32 * i);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vp0[u][i] = load_piece<T>(vbase + (size_t)(ks + 16 * u) * kHeadDim + 32 * i);
+    }
+    if (from_slab) {
+        for (int sp = ks + 16; sp < qa.splits; sp += 16) {   // more than 16 splits (the callers cap them well below)
             const float* src = qa.partial + ((size_t)sp * qa.rows + row) * d + col;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -141,6 +166,7 @@ __global__ __launch_bounds__(256) void k_attention(AttnQ qa, const T* __restrict
 #pragma unroll
                 for (int t = 0; t < 8; ++t) qv[i][t] = fmaf(b8[i][t], on, qv[i][t]);
         }
+        // the 16 slots are added (reduce-scatter + all-gather), which leaves the same bits in every slot
         {
             float flat[32];
 #pragma unroll
@@ -161,19 +187,12 @@ __global__ __launch_bounds__(256) void k_attention(AttnQ qa, const T* __restrict
 #pragma unroll
                 for (int t = 0; t < 8; ++t) qv[i][t] = bf16_to_f32(f32_to_bf16(qv[i][t]));
         }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) load8<T>(reinterpret_cast<const T*>(qa.q) + (size_t)row * d + col + 32 * i, qv[i]);
     }
     const float scale = 0.08838834764831845f;  // 128^-0.5
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int t = 0; t < 8; ++t) qv[i][t] *= scale;
-
-    const size_t hbase = ((size_t)slot * n_heads + head) * cap * kHeadDim + dg * 8;
-    const T* kbase = kc + hbase;
-    const T* vbase = vc + hbase;
 
     float m = -INFINITY, l = 0.f, acc[4][8];
 #pragma unroll
@@ -211,8 +230,15 @@ __global__ __launch_bounds__(256) void k_attention(AttnQ qa, const T* __restrict
     };
 
     // U keys per slot and iteration (16 * U keys per wave), kept packed in registers until they are used
-    constexpr int U = sizeof(T) == 2 ? 4 : 2;
     int key = ks;
+    if (first_full) {   // the round requested above
+        float sc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) sc[u] = score(kp0[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) absorb(sc[u], vp0[u]);
+        key += 16 * U;
+    }
     for (; key + 16 * (U - 1) < nkeys; key += 16 * U) {
         Piece<T> kp[U][4], vp[U][4];
 #pragma unroll
