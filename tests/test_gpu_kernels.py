@@ -258,17 +258,23 @@ def test_attention(hip, dtype, causal, s, base):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("mode", ["plain", "extra_const", "dup_init"])
-def test_gemm_partial_residual_norm(hip, dtype, mode):
-    """Split-K slab -> fused residual update + RMS norm + modulation."""
+@pytest.mark.parametrize("mode", ["plain", "extra_const", "dup_init", "bare"])
+@pytest.mark.parametrize("kind", ["rms", "standard"])
+@pytest.mark.parametrize("N", [768, 1024, 2048, 4096])
+def test_gemm_partial_residual_norm(hip, dtype, mode, kind, N):
+    """Split-K slab -> fused residual update + norm + modulation.  N = 1024 / 2048 / 4096 take the kernel that requests
+    every operand in one round trip (absent operands masked), N = 768 the general one; "bare" = no bias, gate or
+    modulation; "standard" = LayerNorm with weight and bias."""
     torch.manual_seed(11)
-    M, N, K = 64, 1024, 2048
-    rows_total = M if mode == "plain" else 2 * M
+    M, K = 64, 2048
+    rows_total = M if mode in ("plain", "bare") else 2 * M
+    bare = mode == "bare"
     A = torch.randn(M, K).cuda().to(dtype)
     W = (torch.randn(N, K) / math.sqrt(K)).cuda().to(dtype)
     bias = torch.randn(N).cuda().to(dtype)
     gate, const = torch.randn(N).cuda(), torch.randn(N).cuda()
     w = (1 + 0.1 * torch.randn(N)).cuda().to(dtype)
+    nb = (0.2 * torch.randn(N)).cuda().to(dtype)
     shift, scale = (0.3 * torch.randn(N)).cuda(), (0.3 * torch.randn(N)).cuda()
     x0 = torch.randn(rows_total, N).cuda()
     slab = torch.empty(12 * M * N, device="cuda")
@@ -276,17 +282,19 @@ def test_gemm_partial_residual_norm(hip, dtype, mode):
     hip.check(hip.lib.lcmhip_gemm_partial(hip.ptr(A), K, hip.ptr(W), hip.ptr(slab), slab.numel() * 4, C.byref(splits),
                                           M, N, K, hip.dtype_code(dtype), _st(hip)))
     assert splits.value >= 2
-    lin = (A.double() @ W.double().T + bias.double()).cpu()
+    lin = (A.double() @ W.double().T + (0 if bare else bias.double())).cpu()
     x = x0.clone()
     y = torch.empty(rows_total, N, device="cuda", dtype=dtype)
     rows_norm = M if mode == "extra_const" else rows_total
+    layernorm = kind == "standard"
     hip.check(hip.lib.lcmhip_residual_norm(
-        hip.ptr(x), hip.ptr(slab), splits.value, M, hip.ptr(bias), hip.ptr(gate),
+        hip.ptr(x), hip.ptr(slab), splits.value, M, None if bare else hip.ptr(bias), None if bare else hip.ptr(gate),
         hip.ptr(const) if mode == "extra_const" else None, int(mode == "dup_init"), int(mode == "dup_init"),
-        hip.ptr(w), None, hip.ptr(shift), hip.ptr(scale), hip.ptr(y), rows_total, rows_norm, N, 1, 1e-5,
+        hip.ptr(w), hip.ptr(nb) if layernorm else None, None if bare else hip.ptr(shift), None if bare else hip.ptr(scale),
+        hip.ptr(y), rows_total, rows_norm, N, hip.NORM_LAYERNORM if layernorm else hip.NORM_RMS, 1e-5,
         hip.dtype_code(dtype), _st(hip)))
-    g = gate.double().cpu()
-    if mode == "plain":
+    g = torch.ones(N, dtype=torch.float64) if bare else gate.double().cpu()
+    if mode in ("plain", "bare"):
         ref_x = x0.double().cpu() + g * lin
     elif mode == "extra_const":
         ref_x = x0.double().cpu() + torch.cat([g * lin, (g * const.double().cpu()).expand(M, N)])
@@ -295,6 +303,11 @@ def test_gemm_partial_residual_norm(hip, dtype, mode):
     tol = 2e-4 if dtype == torch.float32 else 3e-3
     assert (x.double().cpu() - ref_x).abs().max() <= tol * max(1.0, float(ref_x.abs().max()))
     xr = ref_x[:rows_norm]
-    ref_y = xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-5) * w.double().cpu() * (1 + scale.double().cpu()) + shift.double().cpu()
+    if layernorm:
+        ref_y = torch.nn.functional.layer_norm(xr, (N,), w.double().cpu(), nb.double().cpu(), 1e-5)
+    else:
+        ref_y = xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-5) * w.double().cpu()
+    if not bare:
+        ref_y = ref_y * (1 + scale.double().cpu()) + shift.double().cpu()
     tol_y = 1e-4 if dtype == torch.float32 else 4e-2
     assert (y[:rows_norm].double().cpu() - ref_y).abs().max() <= tol_y
