@@ -8,9 +8,9 @@
 // a lane holds 4 consecutive output columns of one row (vector bias/gate loads, vector stores).
 //   bf16 operands: v_mfma_f32_16x16x32_bf16;  f32 operands: v_mfma_f32_16x16x4_f32 (exact fp32).
 // Two kernels:
-//   k_gemm_dma  bf16, row tiles of 64 or 128 rows (the shapes of the sampling loop): operands staged global -> LDS by
-//               LDS-DMA, three stages, see its own comment;
-//   k_gemm      everything else (fp32; bf16 with at most 32 rows or very wide 64-row problems): a workgroup owns a
+//   k_gemm_dma  bf16, row tiles of 64 (also for fewer rows) or 128 rows: operands staged global -> LDS by LDS-DMA,
+//               three stages, see its own comment;
+//   k_gemm      fp32 (and bf16 when LCMHIP_GEMM_DMA=0): a workgroup owns a
 //               (32*WM rows) x (16*TN*WN weight rows) tile and a range of 512-byte K chunks; a whole chunk of both
 //               operands -- 24..36 16-byte loads per lane, all issued back to back -- is pulled into registers,
 //               written to LDS in full 512-byte rows (+16 B pad: conflict-free 16-byte fragment reads) and consumed
