@@ -210,6 +210,7 @@ def main():
         return seqs, lens
 
     def fence():
+        torch.cuda.synchronize(device)      # this rank's side-stream work is done before it enters the barrier
         if distributed:
             dist.barrier()
         torch.cuda.synchronize(device)
