@@ -114,6 +114,30 @@ def test_gemm_one_tile_per_cu(hip, M, K):
     _check_epilogues(hip, torch.bfloat16, M, 6400, K, False)
 
 
+@pytest.mark.parametrize("M", [65, 96, 128])
+@pytest.mark.parametrize("N,K", [(5632, 2048), (6144, 256), (64, 256), (48 * 16, 768)])
+def test_gemm_swiglu_guarded_window(hip, M, N, K):
+    """SwiGLU with 65..128 bf16 rows (the sampling loop's up-projection) into a row-strided window of a guard
+    buffer: rows past M and columns past N must stay untouched; K = 256 is the shortest pipeline (2 chunks)."""
+    torch.manual_seed(N + K + M)
+    A = torch.randn(M, K).cuda().to(torch.bfloat16)
+    W = (torch.randn(N, K) / math.sqrt(K)).cuda().to(torch.bfloat16)
+    W2 = (torch.randn(N, K) / math.sqrt(K)).cuda().to(torch.bfloat16)
+    b = torch.randn(N).cuda().to(torch.bfloat16)
+    b2 = torch.randn(N).cuda().to(torch.bfloat16)
+    guard = torch.full((M + 3, N + 16), 7.0, device="cuda", dtype=torch.bfloat16)
+    import ctypes
+    # the output is a row-strided window of the guard buffer (ldo = N + 16)
+    hip.check(hip.lib.lcmhip_gemm(hip.ptr(A), K, hip.ptr(W), hip.ptr(W2), hip.ptr(b), hip.ptr(b2), hip.ptr(None),
+                                  ctypes.c_void_p(guard.data_ptr()), guard.stride(0), M, N, K, hip.EPI_SWIGLU,
+                                  hip.dtype_code(A.dtype), hip.ptr(None), 0, _st(hip)))
+    gate = A.double().cpu() @ W.double().cpu().T + b.double().cpu()
+    ref = (A.double().cpu() @ W2.double().cpu().T + b2.double().cpu()) * torch.nn.functional.silu(gate)
+    got = guard.double().cpu()
+    assert (got[:M, :N] - ref).abs().max() <= 3e-2 * max(1.0, float(ref.abs().max()))
+    assert (got[M:] == 7.0).all() and (got[:, N:] == 7.0).all()
+
+
 def test_gemm_one_tile_per_cu_identity(hip):
     """A = I against an asymmetric integer W (exact in bf16): catches a wrong fragment, quadrant or half-tile map
     of the 256 x 256 kernel exactly, and a stale or early LDS read as a wrong integer."""
