@@ -8,7 +8,8 @@ SETS, ITERS = int(os.environ.get("GB_SETS", "13")), 40
 st = _hip.stream_ptr(dev)
 
 def bench(name, M, N, K, mode):
-    A = torch.randn(M, K, device=dev).bfloat16()
+    PAD = int(os.environ.get("GB_PAD", "0"))     # extra elements per activation row (spreads rows over L2 channels)
+    A = torch.randn(M, K + PAD, device=dev).bfloat16()
     Ws = [torch.randn(N, K, device=dev).bfloat16() * 0.02 for _ in range(SETS)]
     W2s = [torch.randn(N, K, device=dev).bfloat16() * 0.02 for _ in range(SETS)] if mode == "swiglu" else None
     slab = torch.empty(12 * M * N, device=dev, dtype=torch.float32)
@@ -16,10 +17,10 @@ def bench(name, M, N, K, mode):
     splits = C.c_int32(0)
     def run(i):
         if mode == "swiglu":
-            _hip.check(_hip.lib.lcmhip_gemm(_hip.ptr(A), K, _hip.ptr(Ws[i]), _hip.ptr(W2s[i]), None, None, None, _hip.ptr(out), N,
+            _hip.check(_hip.lib.lcmhip_gemm(_hip.ptr(A), K + PAD, _hip.ptr(Ws[i]), _hip.ptr(W2s[i]), None, None, None, _hip.ptr(out), N,
                                             M, N, K, _hip.EPI_SWIGLU, _hip.BF16, None, 0, st))
         else:
-            _hip.check(_hip.lib.lcmhip_gemm_partial(_hip.ptr(A), K, _hip.ptr(Ws[i]), _hip.ptr(slab), slab.numel() * 4,
+            _hip.check(_hip.lib.lcmhip_gemm_partial(_hip.ptr(A), K + PAD, _hip.ptr(Ws[i]), _hip.ptr(slab), slab.numel() * 4,
                                                     C.byref(splits), M, N, K, _hip.BF16, st))
     for i in range(SETS):
         run(i)
