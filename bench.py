@@ -11,7 +11,9 @@ outputs are all-gathered once at the end (RCCL), inside the timed region.
 
 Rank 0 prints ONE JSON line with the whole-job throughput plus
   roofline     -- the dominant kernel (weight-streaming GEMM of the denoiser FFN up-projection),
-                  timed live with HIP events on the generation stream in an extra, untimed pass;
+                  timed live with HIP events on the generation stream in an extra, untimed pass
+                  (per-launch event pairs inside the loop for the kernel table, back-to-back launches
+                  on the model's own weights for the kernel's average duration);
   cpu_baseline -- the CPU oracle (a restatement of the reference algorithm) timed on this box's
                   host cores on a bounded sample of the same workload.
 """
@@ -100,7 +102,52 @@ def roofline_pass(model, gen_cls, opt_cls, batch, prompt_len, gen_len, device):
                 avg_launch_us=round(1e3 * dom["total_ms"] / dom["launches"], 3),
                 bytes_per_launch=round(dom["bytes"] / dom["launches"]))
     roof.update(pmc_traffic(dom["name"]))
+    if dom["name"] == "den.ffn_in":
+        # The event pair around a single launch inside the loop also spans about 2 us of launch boundary and event
+        # processing; the kernel's own average duration is taken from back-to-back launches between one event pair
+        # (it agrees with the rocprofv3 average), the in-loop figure is kept beside it.
+        b2b = replay_ffn_in(model, 2 * batch, device)
+        if b2b:
+            roof["in_loop_event_pair_us"] = roof["avg_launch_us"]
+            roof["avg_launch_us"] = b2b["back_to_back_us"]
+            roof["achieved"] = round(roof["bytes_per_launch"] / b2b["back_to_back_us"] / 1e3, 1)
+            roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBS, 4)
+            roof["timing"] = "HIP events around 260 back-to-back launches on the model's 13 weight pairs (cold)"
     return roof, table
+
+
+def replay_ffn_in(model, rows, device, rounds=20):
+    """The dominant kernel alone: the SwiGLU up-projection on the model's own weights, layer after layer (0.6 GB of
+    weights rotate through the caches, so every launch streams from HBM as in the loop), launched back to back
+    between ONE pair of HIP events on the current stream -- kernel time plus the dependent-launch boundary, without
+    the per-launch event pair of the table above."""
+    from lcm import _hip
+
+    sd, layers, i = model.state_dict(), [], 0
+    while f"denoiser.layers.{i}.ffn.gate_proj.weight" in sd:
+        p = f"denoiser.layers.{i}.ffn."
+        layers.append(tuple(sd[p + n] for n in ("gate_proj.weight", "inner_proj.weight", "gate_proj.bias", "inner_proj.bias")))
+        i += 1
+    if not layers:
+        return {}
+    F, K = layers[0][0].shape
+    A = torch.randn(rows, K, device=device).to(model.dtype)
+    out = torch.empty(rows, F, device=device, dtype=model.dtype)
+    st, code = _hip.stream_ptr(device), _hip.dtype_code(model.dtype)
+
+    def sweep():
+        for g, u, bg, bu in layers:
+            _hip.check(_hip.lib.lcmhip_gemm(_hip.ptr(A), K, _hip.ptr(g), _hip.ptr(u), _hip.ptr(bg), _hip.ptr(bu), None,
+                                            _hip.ptr(out), F, rows, F, K, _hip.EPI_SWIGLU, code, None, 0, st))
+    sweep()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(rounds):
+        sweep()
+    e1.record()
+    e1.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / (rounds * len(layers))
+    return {"back_to_back_us": round(us, 3)}
 
 
 # kernel family -> the epilogue id in the HIP symbol rocprofv3 reports for it
