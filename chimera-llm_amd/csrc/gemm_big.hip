@@ -461,13 +461,17 @@ __global__ __launch_bounds__(512) void k_gemm_big256(GemmArgs p) {
     big_epilogue<bf16_t, EPI, 8>(p, acc, smem, wid, m0 + wr * 128, DUAL ? bx * 128 + wc * 32 : bx * 256 + wc * 64, 0, lane);
 }
 
-// K splits for the split-K (slab) form: enough workgroups for the chip, at least 8 K tiles per split, and the
-// splits divide the K tiles
+// K splits for the split-K (slab) form: two workgroups per CU (512; with one per CU a workgroup's four waves have
+// nothing to overlap their barriers with: at 1024 rows ffn_out 46.8 -> 31.6 us, self_ov 22.4 -> 18.3 us, end to end
+// +8 % at 512 documents; 768 and 1024 measured slower again), at least 8 K tiles per split (4: slower), and the splits
+// divide the K tiles.  LCMHIP_BIG_SPLIT_TARGET / LCMHIP_BIG_MIN_KT override both.
 int gemm_big_splits(const GemmArgs& a, int max_splits) {
     const int tiles = (a.N / kBN) * ((a.M + kBM - 1) / kBM);   // counted in 128-row tiles
     const int nk = a.K / 64;
+    static const int target = [] { const char* e = getenv("LCMHIP_BIG_SPLIT_TARGET"); return e ? atoi(e) : 512; }();
+    static const int min_kt = [] { const char* e = getenv("LCMHIP_BIG_MIN_KT"); return e ? atoi(e) : 8; }();
     int s = 1;
-    while (tiles * s < 256 && nk % (s * 2) == 0 && nk / (s * 2) >= 8 && s * 2 <= (max_splits > 0 ? max_splits : 64)) s *= 2;
+    while (tiles * s < target && nk % (s * 2) == 0 && nk / (s * 2) >= min_kt && s * 2 <= (max_splits > 0 ? max_splits : 64)) s *= 2;
     return s;
 }
 
