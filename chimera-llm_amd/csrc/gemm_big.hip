@@ -476,9 +476,11 @@ int gemm_big_splits(const GemmArgs& a, int max_splits) {
 }
 
 // The 128 x 128 kernel pays once its workgroups (tiles x K splits when a slab is available) cover most of the
-// chip; below that the 64 x 64 weight-streaming kernel is faster (measured: M = 256 x N = 2048 14 vs 25 us).
+// chip and there are at least 384 rows; below that the weight-streaming LDS-DMA tiles of gemm.hip are faster (at 256
+// rows the denoiser's ffn_out takes 16.5 against 19.3 us, the sampling loop at 128 documents runs 3.7 % faster; at
+// 384 rows the 128 x 128 kernel wins by 7 %).
 bool gemm_big_applicable(const GemmArgs& a, bool may_split) {
-    static const int min_rows = [] { const char* e = getenv("LCMHIP_BIG_MIN_ROWS"); return e ? atoi(e) : 256; }();
+    static const int min_rows = [] { const char* e = getenv("LCMHIP_BIG_MIN_ROWS"); return e ? atoi(e) : 384; }();
     const int wrows = a.epilogue == LCMHIP_EPI_SWIGLU ? 2 * a.N : a.N;
     if (!(a.dtype == LCMHIP_BF16 && a.M >= min_rows && a.K % 64 == 0 && wrows % kBN == 0 && a.lda % 8 == 0)) return false;
     const int tiles = (wrows / kBN) * ((a.M + kBM - 1) / kBM);
@@ -487,10 +489,11 @@ bool gemm_big_applicable(const GemmArgs& a, bool may_split) {
 }
 
 // epi: LCMHIP_EPI_* or EPI_PARTIAL; splits >= 1 (only with EPI_PARTIAL); m_rows: rows the row tiles must cover
-// The 256 x 256 kernel needs about one tile per CU, no K split, and 32-bit operand offsets.
+// The 256 x 256 kernel needs a tile for most CUs (176 of 256 measured: the SwiGLU projection at 1024 rows takes 56 us
+// against 67 us on 704 tiles of the 128 x 128 kernel), no K split, and 32-bit operand offsets.
 static bool big256_applicable(const GemmArgs& a, int epi, int splits, int m_rows) {
     static const int mode = [] { const char* e = getenv("LCMHIP_BIG256"); return e ? atoi(e) : 1; }();
-    static const int min_tiles = [] { const char* e = getenv("LCMHIP_BIG256_MIN_TILES"); return e ? atoi(e) : 224; }();
+    static const int min_tiles = [] { const char* e = getenv("LCMHIP_BIG256_MIN_TILES"); return e ? atoi(e) : 176; }();
     if (mode == 0 || splits != 1 || epi == EPI_PARTIAL) return false;
     const int wrows = epi == LCMHIP_EPI_SWIGLU ? 2 * a.N : a.N;
     if (wrows % 256 != 0 || a.K % 64 != 0 || a.K < 128) return false;

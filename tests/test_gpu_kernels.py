@@ -98,11 +98,12 @@ def test_gemm_epilogues(hip, dtype, M, N, K, split):
     _check_epilogues(hip, dtype, M, N, K, split)
 
 
-@pytest.mark.parametrize("M", [256, 300, 1000, 2000])
+@pytest.mark.parametrize("M", [256, 300, 384, 400, 1000, 2000])
 @pytest.mark.parametrize("N,K", [(256, 256), (2048, 2048), (1024, 5632)])
 @pytest.mark.parametrize("split", [False, True])
 def test_gemm_many_rows(hip, M, N, K, split):
-    """M >= 256 in bf16 takes the 128 x 128 matrix-core tile kernel (LDS-DMA staging)."""
+    """Several row tiles in bf16: up to 383 rows on the weight-streaming LDS-DMA tile, from 384 rows on the
+    128 x 128 matrix-core tile kernel (when its tiles x splits cover the chip)."""
     _check_epilogues(hip, torch.bfloat16, M, N, K, split)
 
 
