@@ -485,7 +485,10 @@ bool gemm_big_applicable(const GemmArgs& a, bool may_split) {
     if (!(a.dtype == LCMHIP_BF16 && a.M >= min_rows && a.K % 64 == 0 && wrows % kBN == 0 && a.lda % 8 == 0)) return false;
     const int tiles = (wrows / kBN) * ((a.M + kBM - 1) / kBM);
     const int s = may_split ? gemm_big_splits(a, a.max_splits) : 1;
-    return tiles * s >= 192;
+    // a product that needs a K split to fill the chip must reach 320 workgroups (a d x d product at 512 rows has 256:
+    // 12.8 us on the LDS-DMA tile against 15.6 us here), an unsplit one 192 (LCMHIP_BIG_MIN_WG overrides both)
+    static const int min_wg = [] { const char* e = getenv("LCMHIP_BIG_MIN_WG"); return e ? atoi(e) : 0; }();
+    return tiles * s >= (min_wg > 0 ? min_wg : (s > 1 ? 320 : 192));
 }
 
 // epi: LCMHIP_EPI_* or EPI_PARTIAL; splits >= 1 (only with EPI_PARTIAL); m_rows: rows the row tiles must cover
