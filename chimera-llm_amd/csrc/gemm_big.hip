@@ -492,17 +492,24 @@ bool gemm_big_applicable(const GemmArgs& a, bool may_split) {
 }
 
 // epi: LCMHIP_EPI_* or EPI_PARTIAL; splits >= 1 (only with EPI_PARTIAL); m_rows: rows the row tiles must cover
-// The 256 x 256 kernel needs a tile for most CUs (176 of 256 measured: the SwiGLU projection at 1024 rows takes 56 us
-// against 67 us on 704 tiles of the 128 x 128 kernel), no K split, and 32-bit operand offsets.
+// The 256 x 256 kernel (one workgroup per CU) against the 128 x 128 kernel (two per CU): whichever needs less time
+// for its waves of tiles.  A full wave of 256 x 256 tiles takes about 1.6 x a full wave of 128 x 128 tiles (measured
+// on the SwiGLU projection: 50-56 us against 32-34 us; four times the work at 1.15-1.2 x the rate), and a partly
+// filled last wave takes as long as a full one: at 1024 rows 176 tiles in one wave take 56 us against 67 us for 704
+// tiles of 128 x 128 in two.  No K split, 32-bit operand offsets.  LCMHIP_BIG256_MIN_TILES > 0 replaces the estimate
+// by a plain tile count.
 static bool big256_applicable(const GemmArgs& a, int epi, int splits, int m_rows) {
     static const int mode = [] { const char* e = getenv("LCMHIP_BIG256"); return e ? atoi(e) : 1; }();
-    static const int min_tiles = [] { const char* e = getenv("LCMHIP_BIG256_MIN_TILES"); return e ? atoi(e) : 176; }();
+    static const int min_tiles = [] { const char* e = getenv("LCMHIP_BIG256_MIN_TILES"); return e ? atoi(e) : 0; }();
     if (mode == 0 || splits != 1 || epi == EPI_PARTIAL) return false;
     const int wrows = epi == LCMHIP_EPI_SWIGLU ? 2 * a.N : a.N;
     if (wrows % 256 != 0 || a.K % 64 != 0 || a.K < 128) return false;
     if ((size_t)a.M * a.lda * 2 >= (1ull << 31) || (size_t)wrows * a.K * 2 >= (1ull << 31)) return false;
     const int tiles = (wrows / 256) * ((m_rows + 255) / 256);
-    return tiles >= min_tiles;
+    if (min_tiles > 0) return tiles >= min_tiles;
+    const int tiles128 = (wrows / kBN) * ((m_rows + kBM - 1) / kBM);
+    const int waves256 = (tiles + 255) / 256, waves128 = (tiles128 + 511) / 512;
+    return 16 * waves256 < 10 * waves128;
 }
 
 static int launch_gemm_big256(const GemmArgs& a_in, int epi, int m_rows, hipStream_t st) {

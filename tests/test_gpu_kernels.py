@@ -107,11 +107,13 @@ def test_gemm_many_rows(hip, M, N, K, split):
     _check_epilogues(hip, torch.bfloat16, M, N, K, split)
 
 
-@pytest.mark.parametrize("M", [2049, 3000])
+@pytest.mark.parametrize("M", [2049, 2304, 3000])
 @pytest.mark.parametrize("K", [256, 768, 2048])
 def test_gemm_one_tile_per_cu(hip, M, K):
-    """Enough 256 x 256 tiles for every CU (>= 224): the 8-wave kernel whose LDS-DMA stays in flight across
-    barriers; K = 256 is the shortest pipeline the interface allows (4 K tiles), M is ragged against the 256-row tile."""
+    """225 tiles of 256 x 256 (M = 2049, ragged against the 256-row tile; 2304: exact) fit one wave of the 8-wave
+    kernel whose LDS-DMA stays in flight across barriers, which is then chosen over two waves of 128 x 128 tiles;
+    K = 256 is the shortest pipeline the interface allows (4 K tiles).  M = 3000 (300 tiles, two waves) goes to the
+    128 x 128 kernel."""
     _check_epilogues(hip, torch.bfloat16, M, 6400, K, False)
 
 
