@@ -26,13 +26,37 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 }  // namespace
 
+// Residual values of one 32-row round of a wave's output tile, in the lane order in which big_epilogue stores it
+// (RESID only): requested ahead of the round -- round 0 by the kernel itself before the tile is staged (requesting
+// it earlier, with the DMA of the last K tile, measured the same: the read-modify-write is bound by its bytes).
+template <int EPI, bool DUAL>
+__host__ __device__ constexpr int big_resid_rounds() {
+    return EPI == LCMHIP_EPI_RESID ? 32 / (64 / ((DUAL ? 32 : 64) / 4)) : 1;
+}
+template <int EPI, bool DUAL>
+__device__ __forceinline__ void big_load_resid(const GemmArgs& p, int m_wave0, int n_wave0, int half, int lane,
+                                               float4 (&o)[big_resid_rounds<EPI, DUAL>()]) {
+    if constexpr (EPI == LCMHIP_EPI_RESID) {
+        constexpr int NC = DUAL ? 32 : 64, LPR = NC / 4, RPP = 64 / LPR;
+        const int n = n_wave0 + (lane % LPR) * 4;
+#pragma unroll
+        for (int ps = 0; ps < 32 / RPP; ++ps) {
+            const int m = m_wave0 + 32 * half + ps * RPP + lane / LPR;
+            o[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < p.M + p.extra_rows)
+                o[ps] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.out) + (size_t)m * p.ldo + n);
+        }
+    }
+}
+
 // Epilogue of the many-row kernels.  In the accumulators a lane holds 4 columns of 16 different rows, so storing
 // from there touches 16 rows x 32..64 bytes per instruction.  Each wave instead passes its (16 TM) x 64 tile through
 // its own piece of the (now idle) staging memory, 32 rows at a time, and stores row-contiguous 128..256-byte segments;
 // bias and activations are applied on the way in, the residual update (read-modify-write) and row maps on the way out.
 template <typename T, int EPI, int TM>
 __device__ __forceinline__ void big_epilogue(const GemmArgs& p, const f32x4 (&acc)[4][TM], char* smem, int wid,
-                                             int m_wave0, int n_wave0, int split, int lane) {
+                                             int m_wave0, int n_wave0, int split, int lane,
+                                             float4 (&res_cur)[big_resid_rounds<EPI, EPI == LCMHIP_EPI_SWIGLU>()]) {
     constexpr bool DUAL = (EPI == LCMHIP_EPI_SWIGLU);
     constexpr int TNO = DUAL ? 2 : 4;            // output column tiles of the wave
     constexpr int NC = 16 * TNO;                 // output columns of the wave
@@ -51,6 +75,11 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& p, const f32x4 (&ac
             bv[tn][r] = (EPI != EPI_PARTIAL && bias) ? Elem<T>::load(bias + n) : 0.f;
             bv2[tn][r] = (DUAL && bias2) ? Elem<T>::load(bias2 + n) : 0.f;
         }
+    // RESID: the residual values of a 32-row round are requested one round ahead (round 0 by the caller, see
+    // big_resid_rounds / big_load_resid), so that the read-modify-write does not wait for a memory round trip per round
+    constexpr int RPASS = big_resid_rounds<EPI, DUAL>();
+    float4 res_next[RPASS];
+    auto load_resid = [&](int half, float4 (&o)[RPASS]) { big_load_resid<EPI, DUAL>(p, m_wave0, n_wave0, half, lane, o); };
 #pragma unroll
     for (int half = 0; half < TM / 2; ++half) {
         __syncthreads();   // every wave is done with the staging buffers / with the previous round's tile
@@ -79,6 +108,7 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& p, const f32x4 (&ac
             if constexpr (EPI == LCMHIP_EPI_RESID) {
                 if (p.gate && !p.gate_rows) g = *reinterpret_cast<const float4*>(p.gate + n);
             }
+            if (half + 1 < TM / 2) load_resid(half + 1, res_next);
 #pragma unroll
             for (int ps = 0; ps < 32 / RPP; ++ps) {
                 const int r = ps * RPP + lane / LPR;
@@ -94,7 +124,7 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& p, const f32x4 (&ac
                         g = *reinterpret_cast<const float4*>(p.gate + (size_t)min(max(p.gate_rows[m], 0), p.gate_steps - 1) * p.gate_stride + n);
                     if (real || extra) {
                         float4* dstp = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n);
-                        float4 o = *dstp;
+                        float4 o = res_cur[ps < RPASS ? ps : 0];
                         o.x += g.x * v.x; o.y += g.y * v.y; o.z += g.z * v.z; o.w += g.w * v.w;
                         *dstp = o;
                     }
@@ -108,6 +138,8 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& p, const f32x4 (&ac
                     }
                 }
             }
+#pragma unroll
+            for (int ps = 0; ps < RPASS; ++ps) res_cur[ps] = res_next[ps];
         } else {
             constexpr int LPR = NC / 8, RPP = 64 / LPR;
             const int c = (lane % LPR) * 8, n = n_wave0 + c;
@@ -202,6 +234,7 @@ __global__ __launch_bounds__(128 * WMV) void k_gemm_big(GemmArgs p) {
     const int x_row0 = wm * 64 + frow;
     const int w_row0 = BM + wn * 64 + frow;
 
+    const int m_wave0 = m0 + wm * 64, n_wave0 = DUAL ? bx * (kBN / 2) + wn * 32 : bx * kBN + wn * 64;
     stage(k_begin, 0);
     for (int kt = k_begin; kt < k_end; ++kt) {
         const int buf = (kt - k_begin) & 1;
@@ -233,8 +266,9 @@ __global__ __launch_bounds__(128 * WMV) void k_gemm_big(GemmArgs p) {
     }
 
     static_assert(2 * STAGE >= NWAVES * 32 * 68 * 4, "the epilogue tiles must fit the staging buffers");
-    big_epilogue<bf16_t, EPI, 4>(p, acc, smem, wid, m0 + wm * 64, DUAL ? bx * (kBN / 2) + wn * 32 : bx * kBN + wn * 64,
-                              blockIdx.y, lane);
+    float4 res0[big_resid_rounds<EPI, DUAL>()];
+    big_load_resid<EPI, DUAL>(p, m_wave0, n_wave0, 0, lane, res0);
+    big_epilogue<bf16_t, EPI, 4>(p, acc, smem, wid, m_wave0, n_wave0, blockIdx.y, lane, res0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -458,7 +492,9 @@ __global__ __launch_bounds__(512) void k_gemm_big256(GemmArgs p) {
 #undef LCM_RD_X2
 #undef LCM_MMA8
 
-    big_epilogue<bf16_t, EPI, 8>(p, acc, smem, wid, m0 + wr * 128, DUAL ? bx * 128 + wc * 32 : bx * 256 + wc * 64, 0, lane);
+    float4 res0[big_resid_rounds<EPI, DUAL>()];
+    big_load_resid<EPI, DUAL>(p, m0 + wr * 128, DUAL ? bx * 128 + wc * 32 : bx * 256 + wc * 64, 0, lane, res0);
+    big_epilogue<bf16_t, EPI, 8>(p, acc, smem, wid, m0 + wr * 128, DUAL ? bx * 128 + wc * 32 : bx * 256 + wc * 64, 0, lane, res0);
 }
 
 // K splits for the split-K (slab) form: two workgroups per CU (512; with one per CU a workgroup's four waves have
