@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-1 profile of the default bench command: kernel-trace stats, then two PMC passes on a short run.
+# Profile of the default bench command: kernel-trace stats, then two PMC passes on a short run.
 # The counter passes replay nothing from a graph (LCMHIP_GRAPH=0): one pass with graph replay stopped
 # responding right after start-up.
 set -e
