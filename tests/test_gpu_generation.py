@@ -202,6 +202,35 @@ def test_1_6b_full_batch_properties():
         assert torch.nn.functional.cosine_similarity(u, v, dim=-1).min() >= BF16_COS
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("B", [200, 512])
+def test_1_6b_many_documents_properties(B):
+    """Many documents per GPU (the long-context configuration's batch regime): with 400 / 1024 denoiser rows the
+    products run on the matrix-core kernels (128 x 128 with split-K slabs, 256 x 256 for the SwiGLU projection) or,
+    for the conditional rows only, on several row tiles of the weight-streaming kernel.  Same size-independent
+    properties as at 64 documents: bit-for-bit determinism, and a document generated alone (64-row weight-streaming
+    tile) matches the same document inside the batch to the bf16 bar."""
+    from lcm.models.two_tower_diffusion_lcm import create_two_tower_diffusion_lcm_model, lcm_archs
+    from oracle.weights import synthetic_noise, synthetic_prompts
+    arch = "two_tower_diffusion_lcm_1_6B"
+    model = create_two_tower_diffusion_lcm_model(lcm_archs.get_config(arch), device="cuda:0", dtype=torch.bfloat16)
+    model.init_parameters(seed=3, modulator_std=0.02)
+    P, G = 4, 2
+    x = synthetic_prompts(oracle_mod.load_dummy_normalizer(), B, P, seed=21)
+    nz = synthetic_noise(P + G, B, seed=22)
+    opts = dict(DEFAULT_OPTS, inference_timesteps=40)
+    a, _ = run_hip(arch, None, x, nz, G, opts, dtype=torch.bfloat16, model=model)
+    b, _ = run_hip(arch, None, x, nz, G, opts, dtype=torch.bfloat16, model=model)
+    for ha, hb in zip(a.hypotheses, b.hypotheses):
+        assert ha[0].seq.shape == (P + G, 1024) and torch.equal(ha[0].seq, hb[0].seq)
+        assert torch.isfinite(ha[0].seq.float()).all()
+    for i in (0, B // 2 + 1, B - 1):
+        single, _ = run_hip(arch, None, x[i:i + 1], nz[:, i:i + 1], G, opts, dtype=torch.bfloat16, model=model)
+        u, v = single.hypotheses[0][0].seq.float()[P:], a.hypotheses[i][0].seq.float()[P:]
+        assert torch.nn.functional.cosine_similarity(u, v, dim=-1).min() >= BF16_COS
+    del model
+
+
 def test_graph_replay_equals_eager(monkeypatch):
     """On a non-default stream the denoising loop is recorded into a graph once per active-document count and
     replayed; the outputs must equal the eager launches bit for bit, also when documents leave the batch
