@@ -53,6 +53,31 @@ def test_mini_bf16():
     assert cos >= BF16_COS, (worst, cos)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_mini_long_ragged_prompts(dtype):
+    """Long contexts (the long-context configuration's regime at a size the oracle finishes quickly): prompts of
+    300 / 283 / 300 sentences, so the prefill runs several 64-query blocks per document, decoding attends over
+    ~300 cached positions, and the cross-attention over 301 keys (many rounds of 16 plus a ragged tail)."""
+    arch = "mini_two_tower_diffusion_lcm"
+    lens = [300, 283, 300]
+    cfg, sd, x, nz = make_problem(arch, 3, 300, 2, prompt_lens=lens, mod_gain=4.0, qk_gain=1.0)
+    opts = dict(DEFAULT_OPTS, inference_timesteps=40)
+    if dtype == torch.bfloat16:
+        sd = {k: v.bfloat16().float() for k, v in sd.items()}
+        x = x.bfloat16().float()
+    ref = run_oracle(cfg, sd, x, nz, 2, opts, prompt_lens=lens)
+    out, _ = run_hip(arch, sd, x, nz, 2, opts, dtype=dtype, prompt_lens=lens)
+    assert [h[0].seq.shape[0] for h in out.hypotheses] == [n + 2 for n in lens]
+    worst, cos = 0.0, 1.0
+    for n, hh, hr in zip(lens, out.hypotheses, ref):
+        w, c = compare([hh], [hr], sd, start=n)
+        worst, cos = max(worst, w), min(cos, c)
+    if dtype == torch.float32:
+        assert worst <= FP32_MAX_ABS and cos >= FP32_COS, (worst, cos)
+    else:
+        assert cos >= BF16_COS, (worst, cos)
+
+
 def test_ragged_prompts_and_early_finish():
     """Ragged prompts: rows still inside their prompt keep the prompt embedding, documents finish at
     different steps (prompt_len + max_gen_len) and leave the batch."""
