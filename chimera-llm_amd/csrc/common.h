@@ -134,6 +134,9 @@ struct ProfScope {
     ~ProfScope();
 };
 
+// Most K splits any split-K plan uses (bounds the fp32 partial-tile slabs).
+constexpr int kMaxSplits = 12;
+
 // ---- kernel launchers (implemented in the .hip files) ---------------------------------------------
 struct GemmArgs {
     const void* A; int lda;

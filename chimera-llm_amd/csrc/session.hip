@@ -215,8 +215,6 @@ struct lcmhip_session {
 
 namespace lcmhip {
 
-constexpr int kMaxSplits = 12;
-
 struct Carver {
     char* base;
     size_t off = 0;

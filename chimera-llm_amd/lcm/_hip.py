@@ -20,6 +20,7 @@ FFN_RELU, FFN_SWIGLU = 0, 1
 POS_NONE, POS_LEARNED, POS_ROPE = 0, 1, 2
 PRED = {"sample": 0, "epsilon": 1, "v_prediction": 2}
 EPI_STORE, EPI_STORE_F32, EPI_RELU, EPI_SWIGLU, EPI_RESID = 0, 1, 2, 3, 4
+STATIC_SCRATCH_BYTES = 16 << 20      # LCMHIP_STATIC_SCRATCH_BYTES of include/lcmhip.h
 
 EXPORTS = [
     "lcmhip_last_error", "lcmhip_version",
@@ -29,7 +30,7 @@ EXPORTS = [
     "lcmhip_denoise_positions",
     "lcmhip_session_reorder", "lcmhip_session_context_len", "lcmhip_session_num_active",
     "lcmhip_session_read_context", "lcmhip_session_profile_enable", "lcmhip_session_profile",
-    "lcmhip_normalize", "lcmhip_denormalize", "lcmhip_norm_modulate", "lcmhip_gemm", "lcmhip_gemm_partial",
+    "lcmhip_normalize", "lcmhip_denormalize", "lcmhip_norm_modulate", "lcmhip_gemm", "lcmhip_gemm_static", "lcmhip_gemm_partial",
     "lcmhip_residual_norm",
     "lcmhip_ddim_cfg_step", "lcmhip_attention",
 ]
@@ -93,6 +94,7 @@ def _load() -> C.CDLL:
         "lcmhip_denormalize": [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp],
         "lcmhip_norm_modulate": [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp],
         "lcmhip_gemm": [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, C.c_size_t, vp],
+        "lcmhip_gemm_static": [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
         "lcmhip_gemm_partial": [vp, i32, vp, vp, C.c_size_t, C.POINTER(i32), i32, i32, i32, i32, vp],
         "lcmhip_residual_norm": [vp, vp, i32, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
         "lcmhip_ddim_cfg_step": [vp, vp, vp, vp, vp, i32, i32, f32, f32, C.POINTER(DenoiseParams), vp],

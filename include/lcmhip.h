@@ -250,6 +250,20 @@ int lcmhip_gemm(const void* A, int32_t lda, const void* W, const void* W2, const
                 int32_t K, int32_t epilogue, int32_t dtype, float* splitk_ws, size_t splitk_ws_bytes,
                 void* stream);
 
+/* lcmhip_gemm without the workspace argument, for callers that cannot allocate device memory (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.
+ * The split-K slab lives in a static device array of LCMHIP_STATIC_SCRATCH_BYTES that each GPU the library runs
+ * on holds until the process ends; the call allocates and frees nothing.  M * N must not exceed
+ * LCMHIP_STATIC_MAX_OUTPUTS (two fp32 partial tiles must fit), otherwise LCMHIP_ERR_INVALID.  All calls on one
+ * GPU share that GPU's array: calls that overlap on one GPU (different streams or threads) race; calls on one
+ * stream are ordered.  Nothing in the array has to be zero: every element a call reads it has written first.
+ * Results equal lcmhip_gemm's with a workspace of LCMHIP_STATIC_SCRATCH_BYTES bit for bit. */
+#define LCMHIP_STATIC_SCRATCH_BYTES (16u << 20)
+#define LCMHIP_STATIC_MAX_OUTPUTS (LCMHIP_STATIC_SCRATCH_BYTES / 8u)
+int lcmhip_gemm_static(const void* A, int32_t lda, const void* W, const void* W2, const void* bias,
+                       const void* bias2, const float* gate, void* out, int32_t ldo, int32_t M, int32_t N,
+                       int32_t K, int32_t epilogue, int32_t dtype, void* stream);
+
 /* The residual update + pre-norm of one denoiser sub-block, fed from a split-K slab
  * (lcm_denoiser.py:445-473 / 496-521 / 527-546: `seqs = residual + gate * block(...)` followed
  * by the next block's `layer_norm(seqs) * (1 + scale) + shift`).
