@@ -46,8 +46,58 @@ def parse():
     ap.add_argument("--arch", default=ARCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-sentence-steps", type=int, default=1)
+    ap.add_argument("--cpu-sentence-steps", type=int, default=3,
+                    help="generated sentences per document the CPU baseline runs after its prefill")
+    ap.add_argument("--no-check", action="store_true", help="skip the cross-check of the timed output")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="ranks only rendezvous over gloo on the CPU and report the world size (no GPU work)")
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`--gpus N` without a launcher around it: start N ranks as ONE child (`python -m torch.distributed.run`)
+    and leave with its exit code.  This parent never touches the GPU, so nothing that has initialised the GPU is
+    ever replaced or forked.  Under a launcher (WORLD_SIZE set) the world size must equal --gpus."""
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is not None:
+        if int(world_env) != args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world_env} ranks", file=sys.stderr)
+            sys.exit(2)
+        return
+    if args.gpus == 1:
+        return
+    import socket
+    import subprocess
+    if not args.launcher_selftest and not os.environ.get("LCM_BENCH_ONE_DEVICE"):
+        n_dev = torch.cuda.device_count()        # counting devices does not initialise the GPU
+        if n_dev < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) are visible", file=sys.stderr)
+            sys.exit(2)
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
+
+
+def launcher_selftest(args):
+    """What the launcher hands every rank, checked without a GPU: rendezvous over gloo, gather the ranks."""
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo")
+        ranks = [None] * world
+        dist.all_gather_object(ranks, dist.get_rank())
+        n = dist.get_world_size()
+    else:
+        ranks, n = [0], 1
+    assert n == args.gpus and sorted(ranks) == list(range(n)), (n, ranks)
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(json.dumps({"launcher_selftest": True, "n_gpus": n, "ranks": sorted(ranks)}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def make_noise(gen_len, batch, first_doc, device):
@@ -150,6 +200,46 @@ def replay_ffn_in(model, rows, device, rounds=20):
     return {"back_to_back_us": round(us, 3)}
 
 
+def whole_step_roofline(model, batch, prompt_len, gen_len, seconds_per_job):
+    """The whole job against the HBM roof: algorithmic bytes of one executed diffusion step -- every denoiser
+    weight once (shared by all rows) plus the cross-attention keys and values of the conditional rows at the mean
+    context length -- over the job's wall time per executed diffusion step (which also carries the contextualizer
+    and the host loop)."""
+    c = model.config
+    d, D, F, L = c.model_dim, c.sonar_embed_dim, c.denoiser.allocated_ffn_dim(), c.denoiser.num_layers
+    es = 2 if model.dtype == torch.bfloat16 else 4
+    n_ffn = 3 if c.denoiser.use_swiglu else 2
+    weights = (2 * D * d + L * (d * d + 2 * d * d + n_ffn * d * F)) * es          # folded W_ov, cross q / o, FFN
+    mean_keys = prompt_len + (gen_len - 1) / 2.0 + 1.0                              # zero slot + context
+    kv = batch * L * 2 * mean_keys * d * es
+    steps = len(model.noise_scheduler.timesteps)
+    ms = 1e3 * seconds_per_job / (gen_len * steps)
+    achieved = (weights + kv) / ms / 1e6
+    return dict(bytes_per_diffusion_step=round(weights + kv), weight_bytes=round(weights), kv_bytes=round(kv),
+                ms_per_diffusion_step=round(ms, 4), achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=round(achieved / HBM_PEAK_GBS, 4))
+
+
+def check_timed_output(model, gen, seqs, noise, prompt_len, gen_len, device, doc=0):
+    """Cross-check of the timed run (side stream, graph replay, batch-wide tile plans) against an independent run
+    on the default stream: document `doc` alone, its first `t` timed output sentences as the prompt, must reproduce
+    timed sentence t from the same noise -- once early and once at the longest context."""
+    from lcm.datasets.batch import EmbeddingsBatch
+
+    out = {"doc": doc, "positions": [], "cosine": [], "bar": 0.999}
+    for t in (prompt_len + 1, prompt_len + gen_len - 1):
+        prompt = seqs[doc:doc + 1, :t].to(model.dtype)
+        nz = noise[t - prompt_len:t - prompt_len + 1, doc:doc + 1]
+        one = gen(EmbeddingsBatch(prompt, None), max_gen_len=1, noise=nz).hypotheses[0][0].seq
+        c, s = model.sonar_normalizer.center.float(), model.sonar_normalizer.scale.float()
+        a, b = (one[t].float() - c) / s, (seqs[doc, t].float() - c) / s
+        out["positions"].append(t)
+        out["cosine"].append(round(float(torch.nn.functional.cosine_similarity(a, b, dim=0)), 6))
+    torch.cuda.synchronize(device)
+    out["pass"] = min(out["cosine"]) >= out["bar"]
+    return out
+
+
 # kernel family -> the epilogue id in the HIP symbol rocprofv3 reports for it
 _PMC_SYMBOL = {"den.ffn_in": "k_gemm_dma<3, 4,", "den.norm_mod": "k_norm_modulate", "den.cross_attn": "k_attention"}
 
@@ -180,35 +270,57 @@ def pmc_traffic(family):
 
 
 def cpu_baseline(batch, prompt_len, sentence_steps):
-    """The oracle (reference algorithm, PyTorch-CPU fp32) on the same workload shape, bounded to
-    `sentence_steps` generated sentences per document after the prefill."""
+    """The oracle (reference algorithm, PyTorch-CPU fp32) on the same workload shape: the prompt prefill, then
+    `sentence_steps` generated sentences per document, each timed on its own; the rate is extrapolated linearly
+    from the mean per-sentence time.  Threads = this job's CPU share (OMP_NUM_THREADS on the GPU box, else every
+    core the process may run on)."""
     import oracle
+    from oracle.model import KVCache
     from oracle.weights import synthetic_noise, synthetic_prompts
 
-    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    host_cpus = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = host_cpus
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or usable
     torch.set_num_threads(cores)
     cfg = oracle.get_arch(ARCH)
     sd = oracle.init_state_dict(cfg, seed=0, mod_gain=10.0)
     model = oracle.OracleTwoTower(cfg, sd)
-    opts = {k: v for k, v in OPTS.items()}
-    gen = oracle.OracleGenerator(model, oracle.GenOptions(**opts))
+    model.prep_for_denoising(oracle.GenOptions(**OPTS))
     x = synthetic_prompts(oracle.load_dummy_normalizer(), batch, prompt_len)
     nz = synthetic_noise(sentence_steps, batch)
-    t0 = time.perf_counter()
-    gen(x, max_gen_len=sentence_steps, noise=nz)
-    dt = time.perf_counter() - t0
-    return dict(value=round(batch * sentence_steps / dt, 3), unit="sentence-embeddings/s", cores=cores, kind="port",
-                sample=f"oracle (PyTorch-CPU fp32 restatement of the reference), {batch} docs x {prompt_len} prompt, "
-                       f"{sentence_steps} generated sentence(s) per doc incl. prefill, 50 executed DDIM steps + CFG; "
-                       f"{dt:.1f} s wall")
+    with torch.inference_mode():
+        cache = KVCache(prompt_len + sentence_steps)
+        t0 = time.perf_counter()
+        context = model.encode(model.normalize(x[:, :prompt_len - 1]), cache)      # generator.py:222-259
+        cache.increment_step_nr(prompt_len - 1)
+        t_prefill = time.perf_counter() - t0
+        last, per_step = x[:, prompt_len - 1:prompt_len], []
+        for g in range(sentence_steps):
+            t0 = time.perf_counter()
+            last, context = model.predict_next_sentence(last, context, cache, nz[g].unsqueeze(1))
+            per_step.append(time.perf_counter() - t0)
+    mean_step = sum(per_step) / len(per_step)
+    return dict(value=round(batch / mean_step, 3), unit="sentence-embeddings/s", cores=cores, kind="port",
+                host_logical_cpus=host_cpus, prefill_s=round(t_prefill, 2), per_sentence_step_s=[round(t, 2) for t in per_step],
+                sample=f"oracle (PyTorch-CPU fp32 restatement of the reference), {batch} docs x {prompt_len} prompt sentences: "
+                       f"prefill {t_prefill:.1f} s, then {sentence_steps} generated sentences per doc (context {prompt_len}.."
+                       f"{prompt_len + sentence_steps - 1}) at 50 executed DDIM steps + CFG, {mean_step:.1f} s each on {cores} threads "
+                       f"(the host shows {host_cpus} logical CPUs); value = docs / mean sentence-step time, i.e. the 128-sentence job "
+                       f"extrapolated linearly without its prefill -- the reference re-projects the cross-attention keys/values of "
+                       f"the whole context at every diffusion step, so its later sentences are slower than this sample")
 
 
 def main():
     args = parse()
+    launch_ranks(args)          # returns only in a rank whose launcher's world size equals --gpus (or for --gpus 1)
+    if args.launcher_selftest:
+        return launcher_selftest(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     distributed = world > 1
     # rehearsal on a one-GPU box: LCM_BENCH_BACKEND=gloo LCM_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
     # gathers through the host; the real multi-GPU run uses RCCL ("nccl") with one rank per GPU
@@ -223,6 +335,8 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+        world = dist.get_world_size()
+        assert world == args.gpus, f"--gpus {args.gpus} but the process group has {world} ranks"
 
     from lcm.datasets.batch import EmbeddingsBatch
     from lcm.inference.two_tower_diffusion_lcm import DiffusionLCMGeneratorOptions, TwoTowerDiffusionLCMGenerator
@@ -242,6 +356,9 @@ def main():
     prompts = make_prompts(model, B, P, first_doc, device).to(model.dtype)
     noise = make_noise(G, B, first_doc, device)
     stream = torch.cuda.Stream(device)
+    # weights, normalizer buffers, prompts and noise were produced on the default stream
+    stream.wait_stream(torch.cuda.current_stream(device))
+    torch.cuda.synchronize(device)
 
     def one_step():
         with torch.cuda.stream(stream):
@@ -275,6 +392,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     generated = int((lens.to(torch.int64) - P).sum().item())                 # all ranks' documents after the gather
+    assert seqs.shape[0] == world * B and lens.shape[0] == world * B, (tuple(seqs.shape), world, B)   # every rank's documents arrived
     assert generated == world * B * G, (generated, world, B, G)
     assert torch.isfinite(seqs.float()).all()
 
@@ -291,9 +409,12 @@ def main():
                        "global_batch": world * B, "prompt_len": P, "gen_len": G, "executed_ddim_steps": 50,
                        "parallelism": f"dp{world} by document, one all-gather of outputs"},
         }
+    if rank == 0 and not args.no_check:
+        result["check"] = check_timed_output(model, gen, seqs[:B], noise, P, G, device)
     if rank == 0 and not args.no_roofline:      # the other ranks wait at the final barrier meanwhile
         with torch.cuda.stream(stream):
             roof, table = roofline_pass(model, TwoTowerDiffusionLCMGenerator, DiffusionLCMGeneratorOptions, B, P, G, device)
+        roof["whole_step"] = whole_step_roofline(model, B, P, G, elapsed / args.steps)
         result["roofline"] = roof
         result["kernels"] = table
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -303,6 +424,9 @@ def main():
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and result.get("check") and not result["check"]["pass"]:
+        print("bench.py: the timed output failed its cross-check", file=sys.stderr)
+        sys.exit(1)
 
 
 if __name__ == "__main__":

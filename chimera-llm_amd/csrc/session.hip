@@ -2,6 +2,7 @@
 // caller-provided workspace), the contextualizer append, the denoising loop and the C ABI.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -989,13 +990,17 @@ int lcmhip_denoise(lcmhip_session* s, const float* noise, float* out, float* lat
     if (!graphs_on || st == nullptr || s->prof.enabled || latents_trace != nullptr)
         return denoise_body(s, noise, out, latents_trace, st, nullptr);
     const size_t io_bytes = (size_t)s->n_active * s->model->desc.sonar_dim * 4;
+    const bool dbg = env_flag("LCMHIP_DEBUG_GRAPH");   // one stderr line per graph API call (diagnosing profiler stalls)
+#define LCM_GRAPH_DBG(what) do { if (dbg) { fprintf(stderr, "[lcmhip graph] %s (active %d)\n", what, s->n_active); fflush(stderr); } } while (0)
     auto it = s->graphs.find(s->n_active);
     if (it == s->graphs.end()) {
         if (s->graphs.size() >= 16) drop_graphs(s);   // documents finishing one by one: keep the cache bounded
         hipGraph_t graph = nullptr;
+        LCM_GRAPH_DBG("begin capture");
         LCM_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         const int rc = denoise_body(s, s->noise_buf, s->out_buf, nullptr, st, s->d_cross_keys);
         const hipError_t end = hipStreamEndCapture(st, &graph);
+        LCM_GRAPH_DBG("end capture");
         if (rc != LCMHIP_OK) {
             if (graph) (void)hipGraphDestroy(graph);
             return rc;
@@ -1003,13 +1008,21 @@ int lcmhip_denoise(lcmhip_session* s, const float* noise, float* out, float* lat
         LCM_HIP_CHECK(end);
         hipGraphExec_t exec = nullptr;
         const hipError_t inst = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        LCM_GRAPH_DBG("instantiated");
         (void)hipGraphDestroy(graph);
         LCM_HIP_CHECK(inst);
         it = s->graphs.emplace(s->n_active, exec).first;
     }
     LCM_HIP_CHECK(hipMemcpyAsync(s->noise_buf, noise, io_bytes, hipMemcpyDeviceToDevice, st));
+    LCM_GRAPH_DBG("launch");
     LCM_HIP_CHECK(hipGraphLaunch(it->second, st));
+    LCM_GRAPH_DBG("launched");
     LCM_HIP_CHECK(hipMemcpyAsync(out, s->out_buf, io_bytes, hipMemcpyDeviceToDevice, st));
+    if (dbg) {
+        LCM_HIP_CHECK(hipStreamSynchronize(st));
+        LCM_GRAPH_DBG("replay finished");
+    }
+#undef LCM_GRAPH_DBG
     return LCMHIP_OK;
 }
 
