@@ -20,4 +20,5 @@ from .archs import ArchConfig, get_arch, ARCHS, BaseArchConfig, get_base_arch, B
 from .weights import init_state_dict, load_dummy_normalizer  # noqa: F401
 from .scheduler import DDIMSchedule  # noqa: F401
 from .model import OracleTwoTower, OracleBaseLCM  # noqa: F401
+from .bf16_emu import OracleTwoTowerBf16, OracleBaseLCMBf16, r16, summation_order  # noqa: F401
 from .generator import OracleGenerator, OracleScorer, GenOptions  # noqa: F401
