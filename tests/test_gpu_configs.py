@@ -118,7 +118,7 @@ def test_config2_base_lcm_1_6b_forward():
     from lcm.datasets.batch import EmbeddingsBatch
     from lcm.models.base_lcm import create_base_lcm_model
     arch = "base_lcm_1_6B"
-    cfg, sd, x, _ = make_base_problem(arch, 32, 128, 0)
+    cfg, sd, x, _ = make_base_problem(arch, 32, 128, 0, qk_gain=1.0)
     model = create_base_lcm_model(base_config(arch), device="cuda:0", dtype=torch.bfloat16)
     model.load_state_dict(sd)
     xg = x.cuda().to(torch.bfloat16)
@@ -131,9 +131,11 @@ def test_config2_base_lcm_1_6b_forward():
     full = fwd(slice(0, 32))
     assert full.shape == (32, 128, 1024) and torch.isfinite(full).all()
     assert torch.equal(full, fwd(slice(0, 32)))
-    for i in (0, 17, 31):
-        one = fwd(slice(i, i + 1))[0]
-        assert cos_rows(one, full[i], dim=-1).min() >= BF16_COS
+    alone = {i: fwd(slice(i, i + 1))[0] for i in (0, 1, 17, 31)}
+    for i, one in alone.items():
+        c_alone = float(cos_rows(one, full[i], dim=-1).min())
+        print(f"base_lcm_1_6B row {i} alone vs in the batch of 32: min cosine over 128 positions {c_alone:.6f}")
+        assert c_alone >= BF16_COS, (i, c_alone)
     sub = fwd(slice(0, 2)).cpu()
     x16 = O.r16(x[:2])
     sd16 = {k: O.r16(v) for k, v in sd.items()}
@@ -150,6 +152,12 @@ def test_config2_base_lcm_1_6b_forward():
           f"HIP-emulation {d_he:.4f}, emulation'-emulation {d_ee:.4f}")
     assert cos_ref >= BF16_COS, cos_ref
     assert d_hr <= NOISE_RATIO * d_er and d_he <= NOISE_RATIO * d_ee, (d_hr, d_er, d_he, d_ee)
+    # different tile plans (1, 2 or 32 documents) are different summation orders: their drift is bounded by the same floor
+    for i in (0, 1):
+        d_alone = rms(alone[i].cpu(), full[i].cpu())
+        d_sub = rms(sub[i], full[i].cpu())
+        print(f"  row {i}: rms alone-vs-batch {d_alone:.4f}, pair-vs-batch {d_sub:.4f} (floor {d_ee:.4f})")
+        assert d_alone <= NOISE_RATIO * d_ee and d_sub <= NOISE_RATIO * d_ee, (i, d_alone, d_sub, d_ee)
     del model
 
 
