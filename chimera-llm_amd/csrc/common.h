@@ -229,6 +229,9 @@ struct DdimScalars {
     float clip_sample_range;         // < 0: off
     int prediction_type;
     int mode;                        // 0: plain step on out_cond with prediction_type; 1: CFG (eps space)
+    float sigma;                     // eta * sqrt(variance_t): weight of the variance noise (0: deterministic)
+    float thr_ratio;                 // dynamic thresholding quantile; < 0: off
+    float thr_max;                   // sample_max_value
 };
 // Optional inputs / outputs of the fused step: the model output still sitting in the split-K slab of the final
 // projection ([splits][rows_total][dim]; conditional rows first, unconditional rows `rows` further down) with its
@@ -240,12 +243,13 @@ struct DdimIO {
     const void* bias = nullptr;
     void* prev_cast = nullptr;
     int bf16 = 0;                    // dtype of bias and prev_cast
+    const float* variance_noise = nullptr;   // (rows, dim) N(0, 1) draws, required when sigma > 0
 };
 int launch_ddim_step(const float* sample, const float* out_c, const float* out_u, float* prev, float* x0, int rows,
                      int dim, const DdimScalars& sc, hipStream_t st, const DdimIO* io = nullptr);
 // Final: y = x0 * scale + center (T-typed center/scale) -> fp32
 int launch_denormalize_f32_out(const float* x0, const void* center, const void* scale, float* y, int64_t rows,
-                               int dim, int dtype, hipStream_t st);
+                               int dim, int dtype, hipStream_t st, const void* cmin = nullptr, const void* cmax = nullptr);
 // cast != nullptr: also a copy of the latents in `dtype` (the first step's initial projection reads it)
 int launch_init_latents(const float* noise, float* lat, int64_t n, float sigma, float clip, hipStream_t st,
                         void* cast = nullptr, int dtype = LCMHIP_F32);

@@ -120,18 +120,19 @@ int launch_normalize_f32_in(const float* x, const void* center, const void* scal
 }
 
 int launch_denormalize_f32_out(const float* x0, const void* center, const void* scale, float* y, int64_t rows,
-                               int dim, int dtype, hipStream_t st) {
+                               int dim, int dtype, hipStream_t st, const void* cmin, const void* cmax) {
     LCM_REQUIRE(dim % 8 == 0, "normalizer: dim must be a multiple of 8");
+    LCM_REQUIRE((cmin == nullptr) == (cmax == nullptr), "normalizer: clip_min and clip_max go together");
     if (rows == 0) return LCMHIP_OK;
     const int64_t n_vec = rows * (dim / 8);
     const int g = normalizer_grid(n_vec, dim / 8);
     if (dtype == LCMHIP_BF16)
         hipLaunchKernelGGL((k_normalizer<float, float, bf16_t, true>), dim3(g), dim3(256), 0, st, x0,
-                           (const bf16_t*)center, (const bf16_t*)scale, (const bf16_t*)nullptr,
-                           (const bf16_t*)nullptr, y, n_vec, dim / 8);
+                           (const bf16_t*)center, (const bf16_t*)scale, (const bf16_t*)cmin,
+                           (const bf16_t*)cmax, y, n_vec, dim / 8);
     else
         hipLaunchKernelGGL((k_normalizer<float, float, float, true>), dim3(g), dim3(256), 0, st, x0,
-                           (const float*)center, (const float*)scale, (const float*)nullptr, (const float*)nullptr,
+                           (const float*)center, (const float*)scale, (const float*)cmin, (const float*)cmax,
                            y, n_vec, dim / 8);
     LCM_HIP_CHECK(hipGetLastError());
     return LCMHIP_OK;
@@ -570,6 +571,8 @@ __global__ __launch_bounds__(256) void k_ddim_step(const float* __restrict__ sam
                                                    float* __restrict__ x0_out, int dim, DdimScalars sc, DdimIO io) {
     constexpr int MAXV = 4;
     __shared__ float red[4];
+    __shared__ float thr_abs[4096];     // |x0| of the row (dynamic thresholding only)
+    __shared__ float thr_pick[2];
     const size_t base = (size_t)blockIdx.x * dim;
     const int nv = dim / 4;
     // model output of row `r` (conditional rows first, then the unconditional ones): a finished tensor, or the sum of
@@ -670,17 +673,60 @@ __global__ __launch_bounds__(256) void k_ddim_step(const float* __restrict__ sam
             }
         }
     }
+    // Dynamic thresholding (ddim.py:242-280): s = clamp(quantile(|x0|, ratio), 1, max); x0 = clamp(x0, -s, s) / s.
+    // The quantile interpolates linearly between the two order statistics around ratio * (dim - 1), like
+    // torch.quantile; order statistics by counting (rank = smaller values + equal values at lower indices).
+    float thr_s = 0.f;
+    if (sc.thr_ratio >= 0.f) {
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int ch = threadIdx.x + i * 256;
+            if (ch < nv) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) thr_abs[ch * 4 + j] = fabsf(x0[i][j]);
+            }
+        }
+        __syncthreads();
+        const float pos = sc.thr_ratio * (float)(dim - 1);
+        const int lo = (int)floorf(pos), hi = (int)ceilf(pos);
+        const float frac = pos - (float)lo;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int ch = threadIdx.x + i * 256;
+            if (ch < nv) {
+                for (int j = 0; j < 4; ++j) {
+                    const int idx = ch * 4 + j;
+                    const float a = thr_abs[idx];
+                    int rank = 0;
+                    for (int k = 0; k < dim; ++k) {
+                        const float b = thr_abs[k];
+                        rank += (b < a || (b == a && k < idx)) ? 1 : 0;
+                    }
+                    if (rank == lo) thr_pick[0] = a;
+                    if (rank == hi) thr_pick[1] = a;
+                }
+            }
+        }
+        __syncthreads();
+        thr_s = thr_pick[0] + frac * (thr_pick[1] - thr_pick[0]);
+        thr_s = fminf(fmaxf(thr_s, 1.f), sc.thr_max);
+    }
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int ch = threadIdx.x + i * 256;
         if (ch < nv) {
             float p[4], z[4];
+            float4 vn = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (sc.sigma > 0.f) vn = *reinterpret_cast<const float4*>(io.variance_noise + base + ch * 4);
+            const float vns[4] = {vn.x, vn.y, vn.z, vn.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float ee = e[i][j] * sc.inv_eps_scaling;
                 float z0 = x0[i][j];
-                if (sc.clip_sample_range >= 0.f) z0 = fminf(fmaxf(z0, -sc.clip_sample_range), sc.clip_sample_range);
-                const float pr = sc.sqrt_a_prev * z0 + sc.dir_coef * ee;
+                if (sc.thr_ratio >= 0.f) z0 = fminf(fmaxf(z0, -thr_s), thr_s) / thr_s;
+                else if (sc.clip_sample_range >= 0.f) z0 = fminf(fmaxf(z0, -sc.clip_sample_range), sc.clip_sample_range);
+                float pr = sc.sqrt_a_prev * z0 + sc.dir_coef * ee;
+                if (sc.sigma > 0.f) pr += sc.sigma * vns[j];
                 p[j] = fminf(fmaxf(pr, -sc.clip_noise), sc.clip_noise);
                 z[j] = z0;
             }
@@ -710,6 +756,8 @@ int launch_ddim_step(const float* sample, const float* out_c, const float* out_u
     } else {
         LCM_REQUIRE(out_c != nullptr && (sc.mode == 0 || out_u != nullptr), "ddim: guidance needs the unconditional output");
     }
+    LCM_REQUIRE(sc.sigma <= 0.f || io.variance_noise != nullptr, "ddim: eta > 0 needs variance noise");
+    LCM_REQUIRE(sc.thr_ratio < 0.f || (sc.thr_ratio <= 1.f && sc.thr_max >= 1.f), "ddim: bad thresholding parameters");
     if (rows <= 0) return LCMHIP_OK;
     hipLaunchKernelGGL(k_ddim_step, dim3(rows), dim3(256), 0, st, sample, out_c, out_u, prev, x0, dim, sc, io);
     LCM_HIP_CHECK(hipGetLastError());

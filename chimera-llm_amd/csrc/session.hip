@@ -107,6 +107,8 @@ struct lcmhip_model {
     bool finalized = false;
     const void* center = nullptr;
     const void* scale = nullptr;
+    const void* clip_min = nullptr;     // optional (clipping normalizer, sonar_normalizer/builder.py:126-132)
+    const void* clip_max = nullptr;
     lcmhip::Lin pre_linear, t_fc1, t_fc2, init_proj, final_proj, postnet;
     bool base = false;          // base LCM: frontend -> causal decoder -> postnet, no denoiser tower
     const void* pos_table = nullptr;
@@ -146,12 +148,16 @@ static int get_vec(lcmhip_model* m, const std::string& name, int n, const void**
     return LCMHIP_OK;
 }
 
+// "standard": weight + bias; "rms" and "fp32": weight only; "unit": no parameters (the session substitutes ones)
 static int get_norm(lcmhip_model* m, const std::string& prefix, int d, int kind, NormW* n) {
-    LCM_TRY(get_vec(m, prefix + ".weight", d, &n->w));
-    n->b = nullptr;
+    n->w = n->b = nullptr;
+    if (kind != LCMHIP_NORM_UNIT) LCM_TRY(get_vec(m, prefix + ".weight", d, &n->w));
     if (kind == LCMHIP_NORM_LAYERNORM) LCM_TRY(get_vec(m, prefix + ".bias", d, &n->b));
     return LCMHIP_OK;
 }
+
+// Kernel family of a norm style: everything but RMS is a LayerNorm whose absent parameters are 1 / 0.
+static inline int kernel_norm_kind(int kind) { return kind == LCMHIP_NORM_RMS ? LCMHIP_NORM_RMS : LCMHIP_NORM_LAYERNORM; }
 
 static int get_attn(lcmhip_model* m, const std::string& p, int d, bool out_bias, AttnW* a) {
     LCM_TRY(get_lin(m, p + ".q_proj", d, d, true, &a->q));
@@ -173,7 +179,7 @@ static int check_tower(const lcmhip_tower_desc& t, int d, const char* which) {
     LCM_REQUIRE(t.num_heads >= 2 && d == t.num_heads * 128, std::string(which) + ": head_dim must be 128");
     LCM_REQUIRE(t.num_heads % 4 == 0 || t.num_heads == 2, std::string(which) + ": heads must be 2 or a multiple of 4");
     LCM_REQUIRE(t.ffn_dim % 128 == 0, std::string(which) + ": ffn_dim must be a multiple of 128");
-    LCM_REQUIRE(t.norm_kind == LCMHIP_NORM_LAYERNORM || t.norm_kind == LCMHIP_NORM_RMS, "unknown norm kind");
+    LCM_REQUIRE(t.norm_kind >= LCMHIP_NORM_LAYERNORM && t.norm_kind <= LCMHIP_NORM_UNIT, "unknown norm kind");
     LCM_REQUIRE(t.ffn_kind == LCMHIP_FFN_RELU || t.ffn_kind == LCMHIP_FFN_SWIGLU, "unknown ffn kind");
     return LCMHIP_OK;
 }
@@ -196,6 +202,7 @@ struct lcmhip_session {
     char *act_a = nullptr, *act_q = nullptr, *act_k = nullptr, *act_v = nullptr, *act_o = nullptr, *act_h = nullptr,
          *act_in = nullptr, *act_lat = nullptr;
     float* kept_ctx = nullptr;
+    char* ones = nullptr;                          // model_dim ones in the operand dtype: weight of the "unit" norm style
     float *slab_p = nullptr, *slab_q = nullptr;   // split-K slabs: pending products / internal finishing
     int32_t* d_cross_keys = nullptr;              // device copy of ctx_len + 1 (read by graph-recorded attention launches)
     float *noise_buf = nullptr, *out_buf = nullptr;   // fixed addresses for graph-recorded denoising
@@ -274,6 +281,7 @@ static size_t carve(lcmhip_session* s, char* base) {
     s->slab_p = c.take<float>(s->slab_bytes);
     s->slab_q = c.take<float>(s->slab_bytes);
     s->d_cross_keys = c.take<int32_t>(256);
+    s->ones = c.take<char>(dm * es);
     s->noise_buf = c.take<float>(B * D * 4);
     s->out_buf = c.take<float>(B * D * 4);
     return c.off;
@@ -320,7 +328,8 @@ __global__ void k_slot0_rows(int32_t* slot0_rows, int32_t* slot_map, int n, int 
 template <typename T>
 __global__ __launch_bounds__(128) void k_normalize_gather(const float* __restrict__ x, const T* __restrict__ center,
                                                           const T* __restrict__ scale, T* __restrict__ y, int D,
-                                                          int sc, int s_total, int j0, int apply, float escale) {
+                                                          int sc, int s_total, int j0, int apply, float escale,
+                                                          const T* __restrict__ cmin, const T* __restrict__ cmax) {
     const int r = blockIdx.x;
     const int i = r / sc, jj = r % sc;
     const float* src = x + ((size_t)i * s_total + j0 + jj) * D;
@@ -334,6 +343,13 @@ __global__ __launch_bounds__(128) void k_normalize_gather(const float* __restric
             load8<T>(scale + c, sv);
 #pragma unroll
             for (int t = 0; t < 8; ++t) v[t] = (v[t] - ce[t]) / sv[t];
+            if (cmin != nullptr) {   // clipping normalizer: clamp after centring and scaling
+                float lo[8], hi[8];
+                load8<T>(cmin + c, lo);
+                load8<T>(cmax + c, hi);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) v[t] = fminf(fmaxf(v[t], lo[t]), hi[t]);
+            }
         }
 #pragma unroll
         for (int t = 0; t < 8; ++t) v[t] *= escale;     // frontend embedding scale (1 unless scale_embeddings)
@@ -366,7 +382,7 @@ template <typename T>
 __global__ __launch_bounds__(128) void k_base_out(const float* __restrict__ y, const float* __restrict__ noise,
                                                   const T* __restrict__ center, const T* __restrict__ scale,
                                                   float* __restrict__ out, int D, int sc, int n_tokens, int j0, int all,
-                                                  float temperature) {
+                                                  float temperature, const T* __restrict__ cmin, const T* __restrict__ cmax) {
     const int r = blockIdx.x;
     const int i = r / sc, j = j0 + r % sc;
     if (!all && j != n_tokens - 1) return;
@@ -384,6 +400,13 @@ __global__ __launch_bounds__(128) void k_base_out(const float* __restrict__ y, c
             float ce[8], sv[8];
             load8<T>(center + c, ce);
             load8<T>(scale + c, sv);
+            if (cmin != nullptr) {   // clipping normalizer: clamp before scaling back
+                float lo[8], hi[8];
+                load8<T>(cmin + c, lo);
+                load8<T>(cmax + c, hi);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) v[t] = fminf(fmaxf(v[t], lo[t]), hi[t]);
+            }
 #pragma unroll
             for (int t = 0; t < 8; ++t) v[t] = v[t] * sv[t] + ce[t];
         }
@@ -461,8 +484,8 @@ static int norm(lcmhip_session* s, const char* tag, float* x, const NormW& w, co
     double bytes = rows_norm * (double)d.model_dim * (4.0 + es);
     if (pend) bytes += (double)rows_total * d.model_dim * 4.0 * (1.0 + pend->splits);
     ProfScope ps(&s->prof, tag, bytes, 0.0, st);
-    return launch_norm_modulate(x, w.w, w.b, shift, scale, y, rows_total, rows_norm, d.model_dim, kind, d.norm_eps,
-                                d.dtype, pend, st, steps);
+    return launch_norm_modulate(x, w.w != nullptr ? w.w : s->ones, w.b, shift, scale, y, rows_total, rows_norm, d.model_dim,
+                                kernel_norm_kind(kind), d.norm_eps, d.dtype, pend, st, steps);
 }
 
 static int ffn_in(lcmhip_session* s, const char* tag, const lcmhip_tower_desc& t, const FfnW& f, const void* a, int rows,
@@ -530,6 +553,11 @@ int lcmhip_model_finalize(lcmhip_model* m) {
     if (!m->base || has_tensor(m, nrm + ".center")) {   // a base LCM may have no normalizer (abstract_lcm/builder.py:92-101)
         LCM_TRY(get_vec(m, nrm + ".center", D, &m->center));
         LCM_TRY(get_vec(m, nrm + ".scale", D, &m->scale));
+        m->clip_min = m->clip_max = nullptr;
+        if (has_tensor(m, nrm + ".clip_min") || has_tensor(m, nrm + ".clip_max")) {
+            LCM_TRY(get_vec(m, nrm + ".clip_min", D, &m->clip_min));
+            LCM_TRY(get_vec(m, nrm + ".clip_max", D, &m->clip_max));
+        }
     }
     LCM_TRY(get_lin(m, fe + ".pre_linear", dm, D, !m->base || has_tensor(m, fe + ".pre_linear.bias"), &m->pre_linear));
     m->pos_table = nullptr;
@@ -620,6 +648,12 @@ int lcmhip_session_create(lcmhip_model* m, int32_t max_batch, int32_t max_ctx, i
     LCM_TRY(session_dims(s.get(), m, max_batch, max_ctx, max_steps));
     const size_t need = carve(s.get(), static_cast<char*>(workspace));
     LCM_REQUIRE(bytes >= need, "session_create: workspace too small");
+    {
+        std::vector<float> one(m->desc.model_dim, 1.0f);
+        std::vector<uint16_t> one16(m->desc.model_dim, (uint16_t)0x3f80);   // 1.0 in bf16
+        const void* src = m->desc.dtype == LCMHIP_BF16 ? (const void*)one16.data() : (const void*)one.data();
+        LCM_HIP_CHECK(hipMemcpy(s->ones, src, (size_t)m->desc.model_dim * dtype_size(m->desc.dtype), hipMemcpyHostToDevice));
+    }
     // RoPE angle table, computed the way fairseq2's RotaryEncoder does (fp32 frequencies and angles).
     if (m->desc.context.pos_kind == LCMHIP_POS_ROPE) {
         std::vector<float> c((size_t)s->cap * 64), sn((size_t)s->cap * 64);
@@ -702,11 +736,19 @@ int lcmhip_session_set_schedule(lcmhip_session* s, const int32_t* timesteps, int
                                 int32_t step_ratio, const lcmhip_denoise_params* params, void* stream) {
     LCM_REQUIRE(s && timesteps && alphas_cumprod && params, "set_schedule: null argument");
     LCM_REQUIRE(!s->model->base, "set_schedule: a base LCM has no diffusion schedule");
-    drop_graphs(s);   // recorded loops hold the old schedule's scalars
+    // ---- validate everything before the session is touched: a rejected call leaves the previous schedule intact
     LCM_REQUIRE(n_steps >= 1 && n_steps <= s->max_steps, "set_schedule: more steps than the session was sized for");
-    if (params->ddim_eta != 0.f)
-        return fail(LCMHIP_ERR_UNSUPPORTED, "ddim_eta != 0 (stochastic DDIM) is not implemented");
+    LCM_REQUIRE(num_train_steps >= 1 && step_ratio >= 0, "set_schedule: bad train-step count or step ratio");
+    LCM_REQUIRE(params->ddim_eta >= 0.f, "set_schedule: ddim_eta must not be negative");
     LCM_REQUIRE(params->prediction_type >= 0 && params->prediction_type <= 2, "set_schedule: prediction_type");
+    LCM_REQUIRE(!params->thresholding || (params->dynamic_thresholding_ratio >= 0.f && params->dynamic_thresholding_ratio <= 1.f &&
+                                          params->sample_max_value >= 1.f),
+                "set_schedule: thresholding needs a ratio in [0, 1] and sample_max_value >= 1");
+    for (int i = 0; i < n_steps; ++i)
+        LCM_REQUIRE(timesteps[i] >= 0 && timesteps[i] < num_train_steps, "set_schedule: timestep out of range");
+    // ---- from here on the old schedule is gone; have_schedule is set again only when the new one is complete
+    s->have_schedule = false;
+    drop_graphs(s);   // recorded loops hold the old schedule's scalars
     hipStream_t st = static_cast<hipStream_t>(stream);
     lcmhip_model* m = s->model;
     const lcmhip_model_desc& d = m->desc;
@@ -719,7 +761,6 @@ int lcmhip_session_set_schedule(lcmhip_session* s, const int32_t* timesteps, int
     s->step_mode_rows.assign(n_steps, 0);
     for (int i = 0; i < n_steps; ++i) {
         const int t = timesteps[i];
-        LCM_REQUIRE(t >= 0 && t < num_train_steps, "set_schedule: timestep out of range");
         const int prev = t - step_ratio;                                   // ddim.py:421-423
         const float a_t = alphas_cumprod[t];
         const float a_prev = prev >= 0 ? alphas_cumprod[prev] : final_alpha_cumprod;   // ddim.py:426-431
@@ -728,12 +769,20 @@ int lcmhip_session_set_schedule(lcmhip_session* s, const int32_t* timesteps, int
         sc.sqrt_a_t = sqrtf(a_t);
         sc.sqrt_b_t = sqrtf(b_t);
         sc.sqrt_a_prev = sqrtf(a_prev);
-        sc.dir_coef = sqrtf(1.0f - a_prev);                                // eta = 0: sigma_t = 0 (ddim.py:473-485)
+        // sigma_t = eta * sqrt(variance_t), variance_t = (1 - a_prev) / (1 - a_t) * (1 - a_t / a_prev)  (ddim.py:209-222, 473-485)
+        sc.sigma = 0.f;
+        if (params->ddim_eta > 0.f) {
+            const float variance = ((1.0f - a_prev) / (1.0f - a_t)) * (1.0f - a_t / a_prev);
+            sc.sigma = params->ddim_eta * sqrtf(variance);
+        }
+        sc.dir_coef = sqrtf(1.0f - a_prev - sc.sigma * sc.sigma);
         sc.guidance_scale = params->guidance_scale;
         sc.guidance_rescale = params->guidance_rescale;
         sc.inv_eps_scaling = params->epsilon_scaling > 0.f ? 1.0f / params->epsilon_scaling : 1.0f;
         sc.clip_noise = params->clip_noise;
         sc.clip_sample_range = params->clip_sample ? params->clip_sample_range : -1.0f;
+        sc.thr_ratio = params->thresholding ? params->dynamic_thresholding_ratio : -1.0f;
+        sc.thr_max = params->sample_max_value;
         sc.prediction_type = params->prediction_type;
         // builder.py:385-387, 404-449: no guidance on the step whose timestep is T - 1
         const bool is_max = (t == num_train_steps - 1);
@@ -809,10 +858,12 @@ static int append_impl(lcmhip_session* s, const float* x, int32_t n_tokens, int3
                 ProfScope ps(&s->prof, "ctx.normalize", R * (double)D * (4.0 + es), 0.0, st);
                 if (d.dtype == LCMHIP_BF16)
                     hipLaunchKernelGGL((k_normalize_gather<bf16_t>), dim3(R), dim3(128), 0, st, xg, (const bf16_t*)m->center,
-                                       (const bf16_t*)m->scale, (bf16_t*)s->act_in, D, sc, n_tokens, j0, (normalized || !m->center) ? 0 : 1, d.embed_scale);
+                                       (const bf16_t*)m->scale, (bf16_t*)s->act_in, D, sc, n_tokens, j0, (normalized || !m->center) ? 0 : 1, d.embed_scale,
+                                       (const bf16_t*)m->clip_min, (const bf16_t*)m->clip_max);
                 else
                     hipLaunchKernelGGL((k_normalize_gather<float>), dim3(R), dim3(128), 0, st, xg, (const float*)m->center,
-                                       (const float*)m->scale, (float*)s->act_in, D, sc, n_tokens, j0, (normalized || !m->center) ? 0 : 1, d.embed_scale);
+                                       (const float*)m->scale, (float*)s->act_in, D, sc, n_tokens, j0, (normalized || !m->center) ? 0 : 1, d.embed_scale,
+                                       (const float*)m->clip_min, (const float*)m->clip_max);
                 LCM_HIP_CHECK(hipGetLastError());
             }
             LCM_TRY(gemm(s, "ctx.frontend", s->act_in, D, m->pre_linear, nullptr, nullptr, s->xres, dm, R, LCMHIP_EPI_STORE_F32, st));
@@ -862,10 +913,12 @@ static int append_impl(lcmhip_session* s, const float* x, int32_t n_tokens, int3
                 const float* g_noise = bo->noise ? bo->noise + (size_t)d0 * n_out_pos * D : nullptr;
                 if (d.dtype == LCMHIP_BF16)
                     hipLaunchKernelGGL((k_base_out<bf16_t>), dim3(R), dim3(128), 0, st, s->f32tmp, g_noise, (const bf16_t*)m->center,
-                                       (const bf16_t*)m->scale, g_out, D, sc, n_tokens, j0, bo->all, bo->temperature);
+                                       (const bf16_t*)m->scale, g_out, D, sc, n_tokens, j0, bo->all, bo->temperature,
+                                       (const bf16_t*)m->clip_min, (const bf16_t*)m->clip_max);
                 else
                     hipLaunchKernelGGL((k_base_out<float>), dim3(R), dim3(128), 0, st, s->f32tmp, g_noise, (const float*)m->center,
-                                       (const float*)m->scale, g_out, D, sc, n_tokens, j0, bo->all, bo->temperature);
+                                       (const float*)m->scale, g_out, D, sc, n_tokens, j0, bo->all, bo->temperature,
+                                       (const float*)m->clip_min, (const float*)m->clip_max);
                 LCM_HIP_CHECK(hipGetLastError());
             }
         }
@@ -905,7 +958,7 @@ int lcmhip_session_read_context(lcmhip_session* s, int32_t row, float* out, void
 // The whole sampling loop of one sentence.  `keys_dev` != nullptr makes the attention launches read the key
 // count from device memory (the form that is recorded into a graph and replayed for later sentences).
 static int denoise_body(lcmhip_session* s, const float* noise, float* out, float* latents_trace, hipStream_t st,
-                        const int32_t* keys_dev) {
+                        const int32_t* keys_dev, const float* variance_noise = nullptr) {
     lcmhip_model* m = s->model;
     const lcmhip_model_desc& d = m->desc;
     const lcmhip_tower_desc& td = d.denoiser;
@@ -966,6 +1019,7 @@ static int denoise_body(lcmhip_session* s, const float* noise, float* out, float
             DdimIO io;
             io.partial = fp.partial; io.splits = fp.splits; io.rows_total = rows; io.bias = fp.bias;
             io.prev_cast = s->act_lat; io.bf16 = d.dtype == LCMHIP_BF16 ? 1 : 0;
+            io.variance_noise = variance_noise ? variance_noise + (size_t)si * B * D : nullptr;
             ProfScope ps(&s->prof, "den.ddim_cfg_step", (double)B * D * 4.0 * (3.0 + fp.splits * (rows == 2 * B ? 2.0 : 1.0)), 0.0, st);
             LCM_TRY(launch_ddim_step(lat, nullptr, nullptr, lat_next, s->x0, B, D, sc, st, &io));
         }
@@ -973,15 +1027,24 @@ static int denoise_body(lcmhip_session* s, const float* noise, float* out, float
         if (latents_trace)
             LCM_HIP_CHECK(hipMemcpyAsync(latents_trace + (size_t)si * B * D, lat, (size_t)B * D * 4, hipMemcpyDeviceToDevice, st));
     }
-    return launch_denormalize_f32_out(s->x0, m->center, m->scale, out, B, D, d.dtype, st);
+    return launch_denormalize_f32_out(s->x0, m->center, m->scale, out, B, D, d.dtype, st, m->clip_min, m->clip_max);
 }
 
-int lcmhip_denoise(lcmhip_session* s, const float* noise, float* out, float* latents_trace, void* stream) {
+}  // extern "C"
+
+static int denoise_impl(lcmhip_session* s, const float* noise, const float* variance_noise, float* out,
+                        float* latents_trace, void* stream) {
     LCM_REQUIRE(s && noise && out, "denoise: null argument");
     LCM_REQUIRE(!s->model->base, "denoise: a base LCM has no denoiser (use lcmhip_base_forward)");
     if (!s->have_schedule) return fail(LCMHIP_ERR_STATE, "denoise: call session_set_schedule first");
     LCM_REQUIRE(s->n_active >= 1 && s->ctx_len >= 1, "denoise: empty context (append at least one position first)");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (s->params.ddim_eta > 0.f) {
+        // stochastic DDIM: the per-step draws are an input of every call, so the loop is launched, not replayed
+        if (variance_noise == nullptr)
+            return fail(LCMHIP_ERR_STATE, "denoise: the schedule has ddim_eta > 0; call lcmhip_denoise_stochastic with variance noise");
+        return denoise_body(s, noise, out, latents_trace, st, nullptr, variance_noise);
+    }
     // Graph replay: the loop is ~6000 launches per sentence whose arguments depend only on the schedule and on
     // the number of active documents, so it is recorded once per session and replayed.  Needs a non-default
     // stream (capture is not defined on the legacy stream); per-launch profiling and latent traces run eagerly.
@@ -1024,6 +1087,17 @@ int lcmhip_denoise(lcmhip_session* s, const float* noise, float* out, float* lat
     }
 #undef LCM_GRAPH_DBG
     return LCMHIP_OK;
+}
+
+extern "C" {
+
+int lcmhip_denoise(lcmhip_session* s, const float* noise, float* out, float* latents_trace, void* stream) {
+    return denoise_impl(s, noise, nullptr, out, latents_trace, stream);
+}
+
+int lcmhip_denoise_stochastic(lcmhip_session* s, const float* noise, const float* variance_noise, float* out,
+                              float* latents_trace, void* stream) {
+    return denoise_impl(s, noise, variance_noise, out, latents_trace, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ all positions at once
@@ -1079,10 +1153,12 @@ int lcmhip_denoise_positions(lcmhip_session* s, const float* noisy, const int32_
             // latents of this pass, operand dtype (no normalizer: the caller's latents live in normalized space)
             if (d.dtype == LCMHIP_BF16)
                 hipLaunchKernelGGL((k_normalize_gather<bf16_t>), dim3(R), dim3(128), 0, st, xg, (const bf16_t*)nullptr,
-                                   (const bf16_t*)nullptr, (bf16_t*)s->act_in, D, sc, n_positions, j0, 0, 1.0f);
+                                   (const bf16_t*)nullptr, (bf16_t*)s->act_in, D, sc, n_positions, j0, 0, 1.0f,
+                                   (const bf16_t*)nullptr, (const bf16_t*)nullptr);
             else
                 hipLaunchKernelGGL((k_normalize_gather<float>), dim3(R), dim3(128), 0, st, xg, (const float*)nullptr,
-                                   (const float*)nullptr, (float*)s->act_in, D, sc, n_positions, j0, 0, 1.0f);
+                                   (const float*)nullptr, (float*)s->act_in, D, sc, n_positions, j0, 0, 1.0f,
+                                   (const float*)nullptr, (const float*)nullptr);
             LCM_HIP_CHECK(hipGetLastError());
             // The residual stream is updated by the projections' own epilogues (x += gate[row's step] * (h W^T + b)):
             // with many rows no K split is needed, so nothing has to wait in a slab for the next norm kernel.
@@ -1121,10 +1197,12 @@ int lcmhip_denoise_positions(lcmhip_session* s, const float* noisy, const int32_
             float* g_out = out + (size_t)d0 * n_positions * D;
             if (d.dtype == LCMHIP_BF16)
                 hipLaunchKernelGGL((k_base_out<bf16_t>), dim3(R), dim3(128), 0, st, s->f32tmp, (const float*)nullptr,
-                                   (const bf16_t*)nullptr, (const bf16_t*)nullptr, g_out, D, sc, n_positions, j0, 1, 0.f);
+                                   (const bf16_t*)nullptr, (const bf16_t*)nullptr, g_out, D, sc, n_positions, j0, 1, 0.f,
+                                   (const bf16_t*)nullptr, (const bf16_t*)nullptr);
             else
                 hipLaunchKernelGGL((k_base_out<float>), dim3(R), dim3(128), 0, st, s->f32tmp, (const float*)nullptr,
-                                   (const float*)nullptr, (const float*)nullptr, g_out, D, sc, n_positions, j0, 1, 0.f);
+                                   (const float*)nullptr, (const float*)nullptr, g_out, D, sc, n_positions, j0, 1, 0.f,
+                                   (const float*)nullptr, (const float*)nullptr);
             LCM_HIP_CHECK(hipGetLastError());
         }
     }
@@ -1219,22 +1297,30 @@ int lcmhip_residual_norm(float* x, const float* slab, int32_t splits, int32_t M,
 
 int lcmhip_ddim_cfg_step(const float* sample, const float* out_cond, const float* out_uncond, float* prev_sample,
                          float* pred_x0, int32_t rows, int32_t dim, float alpha_prod_t, float alpha_prod_t_prev,
-                         const lcmhip_denoise_params* p, void* stream) {
+                         const lcmhip_denoise_params* p, const float* variance_noise, void* stream) {
     LCM_REQUIRE(sample && out_cond && prev_sample && pred_x0 && p, "ddim_cfg_step: null argument");
-    if (p->ddim_eta != 0.f) return fail(LCMHIP_ERR_UNSUPPORTED, "ddim_eta != 0 (stochastic DDIM) is not implemented");
+    LCM_REQUIRE(p->ddim_eta >= 0.f, "ddim_cfg_step: ddim_eta must not be negative");
+    LCM_REQUIRE(p->ddim_eta == 0.f || variance_noise != nullptr, "ddim_cfg_step: ddim_eta > 0 needs variance noise");
     DdimScalars sc{};
     sc.sqrt_a_t = sqrtf(alpha_prod_t);
     sc.sqrt_b_t = sqrtf(1.0f - alpha_prod_t);
     sc.sqrt_a_prev = sqrtf(alpha_prod_t_prev);
-    sc.dir_coef = sqrtf(1.0f - alpha_prod_t_prev);
+    sc.sigma = 0.f;
+    if (p->ddim_eta > 0.f)
+        sc.sigma = p->ddim_eta * sqrtf(((1.0f - alpha_prod_t_prev) / (1.0f - alpha_prod_t)) * (1.0f - alpha_prod_t / alpha_prod_t_prev));
+    sc.dir_coef = sqrtf(1.0f - alpha_prod_t_prev - sc.sigma * sc.sigma);
     sc.guidance_scale = p->guidance_scale;
     sc.guidance_rescale = p->guidance_rescale;
     sc.inv_eps_scaling = p->epsilon_scaling > 0.f ? 1.0f / p->epsilon_scaling : 1.0f;
     sc.clip_noise = p->clip_noise;
     sc.clip_sample_range = p->clip_sample ? p->clip_sample_range : -1.0f;
+    sc.thr_ratio = p->thresholding ? p->dynamic_thresholding_ratio : -1.0f;
+    sc.thr_max = p->sample_max_value;
     sc.prediction_type = p->prediction_type;
     sc.mode = out_uncond ? 1 : 0;
-    return launch_ddim_step(sample, out_cond, out_uncond, prev_sample, pred_x0, rows, dim, sc, static_cast<hipStream_t>(stream));
+    DdimIO io;
+    io.variance_noise = variance_noise;
+    return launch_ddim_step(sample, out_cond, out_uncond, prev_sample, pred_x0, rows, dim, sc, static_cast<hipStream_t>(stream), &io);
 }
 
 int lcmhip_attention(const void* q, const void* k_cache, const void* v_cache, const int32_t* slot_map, void* out,

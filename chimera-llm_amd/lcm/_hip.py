@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LCMHIP_LIB") or os.path.join(_HERE, "liblcm_hip.so")
 
 F32, BF16 = 0, 1
-NORM_LAYERNORM, NORM_RMS = 0, 1
+NORM_LAYERNORM, NORM_RMS, NORM_FP32, NORM_UNIT = 0, 1, 2, 3
 FFN_RELU, FFN_SWIGLU = 0, 1
 POS_NONE, POS_LEARNED, POS_ROPE = 0, 1, 2
 PRED = {"sample": 0, "epsilon": 1, "v_prediction": 2}
@@ -26,7 +26,7 @@ EXPORTS = [
     "lcmhip_last_error", "lcmhip_version",
     "lcmhip_model_create", "lcmhip_model_bind_weight", "lcmhip_model_finalize", "lcmhip_model_destroy",
     "lcmhip_session_workspace_bytes", "lcmhip_session_create", "lcmhip_session_destroy",
-    "lcmhip_session_set_schedule", "lcmhip_session_reset", "lcmhip_context_append", "lcmhip_base_forward", "lcmhip_denoise",
+    "lcmhip_session_set_schedule", "lcmhip_session_reset", "lcmhip_context_append", "lcmhip_base_forward", "lcmhip_denoise", "lcmhip_denoise_stochastic",
     "lcmhip_denoise_positions",
     "lcmhip_session_reorder", "lcmhip_session_context_len", "lcmhip_session_num_active",
     "lcmhip_session_read_context", "lcmhip_session_profile_enable", "lcmhip_session_profile",
@@ -51,7 +51,8 @@ class ModelDesc(C.Structure):
 class DenoiseParams(C.Structure):
     _fields_ = [("guidance_scale", C.c_float), ("guidance_rescale", C.c_float), ("ddim_eta", C.c_float),
                 ("epsilon_scaling", C.c_float), ("clip_noise", C.c_float), ("init_noise_sigma", C.c_float),
-                ("prediction_type", C.c_int32), ("clip_sample", C.c_int32), ("clip_sample_range", C.c_float)]
+                ("prediction_type", C.c_int32), ("clip_sample", C.c_int32), ("clip_sample_range", C.c_float),
+                ("thresholding", C.c_int32), ("dynamic_thresholding_ratio", C.c_float), ("sample_max_value", C.c_float)]
 
 
 class ProfileRow(C.Structure):
@@ -83,6 +84,7 @@ def _load() -> C.CDLL:
         "lcmhip_context_append": [vp, vp, i32, i32, vp],
         "lcmhip_base_forward": [vp, vp, i32, i32, vp, f32, i32, vp, vp],
         "lcmhip_denoise": [vp, vp, vp, vp, vp],
+        "lcmhip_denoise_stochastic": [vp, vp, vp, vp, vp, vp],
         "lcmhip_denoise_positions": [vp, vp, vp, i32, vp, vp, vp, vp],
         "lcmhip_session_reorder": [vp, C.POINTER(i32), i32, vp],
         "lcmhip_session_context_len": [vp],
@@ -97,7 +99,7 @@ def _load() -> C.CDLL:
         "lcmhip_gemm_static": [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
         "lcmhip_gemm_partial": [vp, i32, vp, vp, C.c_size_t, C.POINTER(i32), i32, i32, i32, i32, vp],
         "lcmhip_residual_norm": [vp, vp, i32, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
-        "lcmhip_ddim_cfg_step": [vp, vp, vp, vp, vp, i32, i32, f32, f32, C.POINTER(DenoiseParams), vp],
+        "lcmhip_ddim_cfg_step": [vp, vp, vp, vp, vp, i32, i32, f32, f32, C.POINTER(DenoiseParams), vp, vp],
         "lcmhip_attention": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     }
     for name, argtypes in sig.items():

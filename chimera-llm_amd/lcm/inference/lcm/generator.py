@@ -112,6 +112,9 @@ class LCMGenerator:
         if opt.seed:
             torch.manual_seed(opt.seed)
         noise: Optional[Tensor] = kwargs.pop("noise", None)
+        # stochastic DDIM only: (generation steps, diffusion steps, documents, D) N(0, 1) draws, indexed like `noise`
+        self._variance_noise: Optional[Tensor] = kwargs.pop("variance_noise", None)
+        self._variance_step: Optional[Tensor] = None
         if self.takes_option_overrides:
             for k, v in kwargs.items():             # reference :181-183
                 if hasattr(opt, k) and v:
@@ -169,6 +172,9 @@ class LCMGenerator:
                     nz = nz if everyone else nz[active_t]
                 else:
                     nz = None
+                if self._variance_noise is not None:
+                    vn = self._variance_noise[step - P_min]
+                    self._variance_step = vn if everyone else vn[:, active_t]
                 new = self._predict(prev, nz, active_t, everyone)            # (n_act, D) fp32
 
                 # ---- stopping rules (host-side unless an EOS / repetition test needs the embeddings)

@@ -27,7 +27,7 @@ logger = logging.getLogger(__name__)
 class DiffusionLCMGeneratorOptions(LCMGeneratorOptions):
     guidance_scale: float = 1.0           # w of classifier-free guidance; 1 = no guidance
     guidance_rescale: float = 0.0         # phi of CFG-with-rescale (arXiv 2305.08891, alg. 2)
-    ddim_eta: float = 0.0                 # 0 = deterministic DDIM (the only implemented value)
+    ddim_eta: float = 0.0                 # 0 = deterministic DDIM; > 0 adds eta * sigma_t * N(0, 1) at every step
     epsilon_scaling: Optional[float] = None
     initial_noise_scale: float = 1.0
     inference_timesteps: int = 100
@@ -68,7 +68,8 @@ class TwoTowerDiffusionLCMGenerator(LCMGenerator):
         """reference generator.py:261-303"""
         out, self.context = self.model.predict_next_sentence(
             EmbeddingsBatch(prev, None), self.context, temperature=self.temperature,
-            state_bag=self.state_bag, context_state_bag=self.context_state_bag, noise=noise)
+            state_bag=self.state_bag, context_state_bag=self.context_state_bag, noise=noise,
+            variance_noise=getattr(self, "_variance_step", None))
         self.state_bag.increment_step_nr()
         return out.seqs[:, -1]
 

@@ -26,6 +26,8 @@ from lcm.models.two_tower_diffusion_lcm.builder import (
     DeviceSession,
     _ArchRegistry,
     _check_supported,
+    normalizer_config_for,
+    normalizer_spec,
 )
 from lcm.nn.incremental_state import LCMIncrementalStateBag
 from lcm.nn.transformer_config import ProjectionConfig, TransformerConfig
@@ -60,22 +62,25 @@ lcm_archs = _ArchRegistry()
 lcm_arch = lcm_archs.decorator
 
 
-def parameter_spec(config: BaseLCModelConfig) -> List[Tuple[str, Tuple[int, ...], str]]:
+def parameter_spec(config: BaseLCModelConfig,
+                   normalizer: Optional[SonarNormalizerConfig] = None) -> List[Tuple[str, Tuple[int, ...], str]]:
     """(name, shape, kind) of every parameter/buffer, named like the reference's state dict."""
     d, D, tc = config.model_dim, config.sonar_embed_dim, config.lcm
     spec: List[Tuple[str, Tuple[int, ...], str]] = []
     if config.sonar_normalizer_name is not None:
-        spec += [("frontend.sonar_normalizer.center", (D,), "zeros"), ("frontend.sonar_normalizer.scale", (D,), "ones")]
+        spec += normalizer_spec("frontend.sonar_normalizer", normalizer or SonarNormalizerConfig(dim=D))
     spec.append(("frontend.pre_linear.weight", (d, D), "matrix"))
     if config.frontend.pre_linear_bias:
         spec.append(("frontend.pre_linear.bias", (d,), "zeros"))
     if tc.pos_embedding_style == "learned":
         spec.append(("frontend.pos_encoder.weight", (config.max_seq_len, d), "pos"))
     F = tc.allocated_ffn_dim()
+    ln_weight = tc.layer_normalization_style != "unit"
     ln_bias = tc.layer_normalization_style == "standard"
 
     def norm(n: str) -> None:
-        spec.append((f"{n}.weight", (d,), "ones"))
+        if ln_weight:
+            spec.append((f"{n}.weight", (d,), "ones"))
         if ln_bias:
             spec.append((f"{n}.bias", (d,), "zeros"))
 
@@ -128,16 +133,20 @@ class BaseLCModel(AbstractLCModel):
             raise NotImplementedError("postnet activation / weight normalization are not implemented on the HIP path")
         self.model_dim = config.model_dim
         self.sonar_embed_dim = config.sonar_embed_dim
-        self._spec = parameter_spec(config)
+        ncfg = normalizer_config_for(config.sonar_normalizer_name, config.sonar_embed_dim)
+        self._spec = parameter_spec(config, ncfg)
         self._params: Dict[str, Tensor] = {
             name: torch.empty(shape, dtype=dtype, device=device) for name, shape, _ in self._spec}
         self._handle = None
         self.init_parameters(seed if seed is not None else 0)
         normalizer = None
         if config.sonar_normalizer_name is not None:
-            normalizer = SonarNormalizer(SonarNormalizerConfig(dim=config.sonar_embed_dim), device=device, dtype=dtype)
+            normalizer = SonarNormalizer(ncfg, device=device, dtype=dtype)
             normalizer.center = self._params["frontend.sonar_normalizer.center"]
             normalizer.scale = self._params["frontend.sonar_normalizer.scale"]
+            if ncfg.clip_proba is not None:
+                normalizer.clip_min = self._params["frontend.sonar_normalizer.clip_min"]
+                normalizer.clip_max = self._params["frontend.sonar_normalizer.clip_max"]
         self.frontend = _Frontend(normalizer)
         self.sonar_normalizer = normalizer
         self._handle = C.c_void_p()

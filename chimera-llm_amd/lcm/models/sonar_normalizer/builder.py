@@ -27,7 +27,11 @@ class SonarNormalizerConfig:
 
 sonar_normalizer_archs: Dict[str, SonarNormalizerConfig] = {
     "base": SonarNormalizerConfig(),
+    "base_page4k": SonarNormalizerConfig(dim=4 * 1024),
     "clipping": SonarNormalizerConfig(clip_proba=1e-4),
+    # registered so that a card naming them is refused with a clear message instead of an unknown-arch error
+    "base_fft": SonarNormalizerConfig(with_fft=True),
+    "clipping_fft": SonarNormalizerConfig(clip_proba=1e-4, with_fft=True),
 }
 
 

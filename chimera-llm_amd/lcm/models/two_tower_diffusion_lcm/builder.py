@@ -57,7 +57,7 @@ class _ArchRegistry(dict):
 lcm_archs = _ArchRegistry()
 lcm_arch = lcm_archs.decorator
 
-_NORM_KIND = {"standard": _hip.NORM_LAYERNORM, "rms": _hip.NORM_RMS}
+_NORM_KIND = {"standard": _hip.NORM_LAYERNORM, "rms": _hip.NORM_RMS, "fp32": _hip.NORM_FP32, "unit": _hip.NORM_UNIT}
 _POS_KIND = {"none": _hip.POS_NONE, "learned": _hip.POS_LEARNED, "rope": _hip.POS_ROPE}
 TIMESTEP_FREQ_DIM = 256
 
@@ -80,11 +80,38 @@ def _check_supported(name: str, tc: TransformerConfig) -> None:
         raise NotImplementedError(f"{name}: not implemented on the HIP path: {', '.join(bad)}")
 
 
-def parameter_spec(config: TwoTowerDiffusionLCModelConfig) -> List[Tuple[str, Tuple[int, ...], str]]:
+def normalizer_config_for(name: Optional[str], dim: int) -> SonarNormalizerConfig:
+    """Config of the normalizer a model names (reference: abstract_lcm/builder.py:89-101 loads that card, so the
+    model's normalizer has the card's arch, clipping included).  Unknown or absent names give the base arch."""
+    from lcm.models.sonar_normalizer.builder import sonar_normalizer_archs
+    from lcm.utils.card_utils import resolve_card
+    cfg = SonarNormalizerConfig(dim=dim)
+    if name is not None:
+        try:
+            card = resolve_card(name)
+        except ValueError:
+            card = None
+        if card is not None:
+            arch = sonar_normalizer_archs[card.get("model_arch", "base")]
+            cfg = SonarNormalizerConfig(**{**arch.__dict__, "dim": dim})
+    if cfg.with_fft:
+        raise NotImplementedError("FFT normalizer variants are not implemented on the HIP path")
+    return cfg
+
+
+def normalizer_spec(prefix: str, ncfg: SonarNormalizerConfig) -> List[Tuple[str, Tuple[int, ...], str]]:
+    D = ncfg.dim
+    spec = [(f"{prefix}.center", (D,), "zeros"), (f"{prefix}.scale", (D,), "ones")]
+    if ncfg.clip_proba is not None:      # sonar_normalizer/builder.py:111-117: both start at one
+        spec += [(f"{prefix}.clip_min", (D,), "ones"), (f"{prefix}.clip_max", (D,), "ones")]
+    return spec
+
+
+def parameter_spec(config: TwoTowerDiffusionLCModelConfig,
+                   normalizer: Optional[SonarNormalizerConfig] = None) -> List[Tuple[str, Tuple[int, ...], str]]:
     """(name, shape, kind) of every parameter/buffer, named like the reference's state dict."""
     d, D = config.model_dim, config.sonar_embed_dim
-    spec: List[Tuple[str, Tuple[int, ...], str]] = [
-        ("sonar_normalizer.center", (D,), "zeros"), ("sonar_normalizer.scale", (D,), "ones"),
+    spec: List[Tuple[str, Tuple[int, ...], str]] = normalizer_spec("sonar_normalizer", normalizer or SonarNormalizerConfig(dim=D)) + [
         ("encoder_frontend.pre_linear.weight", (d, D), "matrix"), ("encoder_frontend.pre_linear.bias", (d,), "zeros"),
     ]
     if config.context_encoder.pos_embedding_style == "learned":
@@ -92,10 +119,12 @@ def parameter_spec(config: TwoTowerDiffusionLCModelConfig) -> List[Tuple[str, Tu
 
     def stack(prefix: str, tc: TransformerConfig, denoiser: bool) -> None:
         F = tc.allocated_ffn_dim()
-        ln_bias = tc.layer_normalization_style == "standard"
+        ln_weight = tc.layer_normalization_style != "unit"       # lcm/nn/normalization.py:56-70: no learnable parameters
+        ln_bias = tc.layer_normalization_style == "standard"      # "rms" and "fp32" are built with bias=False
 
         def norm(n: str) -> None:
-            spec.append((f"{n}.weight", (d,), "ones"))
+            if ln_weight:
+                spec.append((f"{n}.weight", (d,), "ones"))
             if ln_bias:
                 spec.append((f"{n}.bias", (d,), "zeros"))
 
@@ -171,21 +200,23 @@ class DeviceSession:
                 ddim_eta=float(m.ddim_eta), epsilon_scaling=float(m.epsilon_scaling) if m.epsilon_scaling else 0.0,
                 clip_noise=float(m.clip_noise), init_noise_sigma=float(sch.init_noise_sigma),
                 prediction_type=_hip.PRED[sch.prediction_type], clip_sample=int(sch.config.clip_sample),
-                clip_sample_range=float(sch.config.clip_sample_range))
+                clip_sample_range=float(sch.config.clip_sample_range), thresholding=int(sch.config.thresholding),
+                dynamic_thresholding_ratio=float(sch.config.dynamic_thresholding_ratio),
+                sample_max_value=float(sch.config.sample_max_value))
         else:
             ts = [int(t) for t in timesteps]
             key = ("table", tuple(ts))
             params = _hip.DenoiseParams(
                 guidance_scale=1.0, guidance_rescale=0.0, ddim_eta=0.0, epsilon_scaling=0.0, clip_noise=100.0,
-                init_noise_sigma=1.0, prediction_type=_hip.PRED[sch.prediction_type], clip_sample=0, clip_sample_range=1.0)
+                init_noise_sigma=1.0, prediction_type=_hip.PRED[sch.prediction_type], clip_sample=0, clip_sample_range=1.0,
+                thresholding=0, dynamic_thresholding_ratio=0.995, sample_max_value=1.0)
         if key == self.schedule_key:
             return
         step_ratio = sch.step_ratio if timesteps is None else 1
         ts_arr = (C.c_int32 * len(ts))(*ts)
         ac = sch.alphas_cumprod.tolist()
         ac_arr = (C.c_float * len(ac))(*ac)
-        if sch.config.thresholding:
-            raise NotImplementedError("dynamic thresholding is not implemented on the HIP path")
+        self.schedule_key = None      # a rejected call leaves the session without a usable schedule of this key
         _hip.check(_hip.lib.lcmhip_session_set_schedule(
             self._h, ts_arr, len(ts), ac_arr, len(ac), float(sch.final_alpha_cumprod), step_ratio,
             C.byref(params), self._stream()))
@@ -220,13 +251,20 @@ class DeviceSession:
                                                 float(temperature), int(all_positions), _hip.ptr(out), self._stream()))
         return out
 
-    def denoise(self, noise: Tensor, trace: Optional[Tensor] = None) -> Tensor:
-        """noise: (n_active, D) N(0, 1) draws -> next sentence embedding (n_active, D) fp32."""
+    def denoise(self, noise: Tensor, trace: Optional[Tensor] = None, variance_noise: Optional[Tensor] = None) -> Tensor:
+        """noise: (n_active, D) N(0, 1) draws -> next sentence embedding (n_active, D) fp32.  `variance_noise`
+        (n_steps, n_active, D): the per-step draws of stochastic DDIM (needed when the schedule has ddim_eta > 0)."""
         _hip.require_gpu(noise, "noise")
         nz = noise.float().contiguous()
         assert nz.shape[0] == self.num_active
         out = torch.empty_like(nz)
-        _hip.check(_hip.lib.lcmhip_denoise(self._h, _hip.ptr(nz), _hip.ptr(out), _hip.ptr(trace), self._stream()))
+        if variance_noise is None:
+            _hip.check(_hip.lib.lcmhip_denoise(self._h, _hip.ptr(nz), _hip.ptr(out), _hip.ptr(trace), self._stream()))
+            return out
+        vn = variance_noise.float().contiguous()
+        assert vn.dim() == 3 and vn.shape[1:] == nz.shape, (tuple(vn.shape), tuple(nz.shape))
+        _hip.check(_hip.lib.lcmhip_denoise_stochastic(self._h, _hip.ptr(nz), _hip.ptr(vn), _hip.ptr(out), _hip.ptr(trace),
+                                                      self._stream()))
         return out
 
     def denoise_positions(self, noisy: Tensor, step_index: Tensor, source_lengths: Optional[Tensor] = None,
@@ -316,7 +354,8 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
             raise ValueError("timestep_embed_dim must equal model_dim")
         self.model_dim = config.model_dim
         self.sonar_embed_dim = config.sonar_embed_dim
-        self._spec = parameter_spec(config)
+        ncfg = normalizer_config_for(config.sonar_normalizer_name, config.sonar_embed_dim)
+        self._spec = parameter_spec(config, ncfg)
         self._params: Dict[str, Tensor] = {
             name: torch.empty(shape, dtype=dtype, device=device) for name, shape, _ in self._spec}
         # derived tensors: the denoiser's self-attention always sees one position, where softmax == 1 and the
@@ -329,10 +368,13 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
             self._derived[f"denoiser.layers.{i}.self_attn.ov_proj.bias"] = torch.empty((d,), dtype=dtype, device=device)
         self._handle = None
         self.init_parameters(seed if seed is not None else 0)
-        self.sonar_normalizer = SonarNormalizer(SonarNormalizerConfig(dim=config.sonar_embed_dim), device=device, dtype=dtype)
+        self.sonar_normalizer = SonarNormalizer(ncfg, device=device, dtype=dtype)
         # the normalizer's buffers ARE the model's tensors (one storage, like a registered submodule)
         self.sonar_normalizer.center = self._params["sonar_normalizer.center"]
         self.sonar_normalizer.scale = self._params["sonar_normalizer.scale"]
+        if ncfg.clip_proba is not None:
+            self.sonar_normalizer.clip_min = self._params["sonar_normalizer.clip_min"]
+            self.sonar_normalizer.clip_max = self._params["sonar_normalizer.clip_max"]
         self.noise_scheduler = DDIMScheduler(config.noise_scheduler)
         self._handle = C.c_void_p()
         self._bind()
@@ -439,15 +481,17 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
         self.do_classifier_free_guidance = self.guidance_scale != 1.0
         self.noise_scheduler.set_timesteps(self.timesteps, device=self.device)
         self.noise_scheduler.init_noise_sigma = self.initial_noise_scale
-        if o.thresholding:
-            raise NotImplementedError("dynamic thresholding is not implemented on the HIP path")
-        if o.ddim_eta != 0.0:
-            raise NotImplementedError("ddim_eta != 0 (stochastic DDIM) is not implemented on the HIP path")
+        if o.thresholding:          # reference builder.py:234-242: the options override the scheduler's config
+            self.noise_scheduler.config.thresholding = o.thresholding
+            self.noise_scheduler.config.dynamic_thresholding_ratio = o.dynamic_thresholding_ratio
+            self.noise_scheduler.config.sample_max_value = o.sample_max_value
 
     def _schedule_key(self):
         s = self.noise_scheduler
+        c = s.config
         return (tuple(s.timesteps.tolist()), self.guidance_scale, self.guidance_rescale, self.ddim_eta,
-                self.epsilon_scaling, self.clip_noise, s.init_noise_sigma, s.prediction_type)
+                self.epsilon_scaling, self.clip_noise, s.init_noise_sigma, s.prediction_type,
+                c.clip_sample, c.clip_sample_range, c.thresholding, c.dynamic_thresholding_ratio, c.sample_max_value)
 
     def acquire_session(self, max_batch: int, max_ctx: int, timesteps: Optional[List[int]] = None) -> DeviceSession:
         if timesteps is None:
@@ -524,10 +568,11 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
                               state_bag: Optional[LCMIncrementalStateBag] = None,
                               context_state_bag: Optional[LCMIncrementalStateBag] = None,
                               noise: Optional[Tensor] = None, trace: Optional[Tensor] = None,
-                              **kwargs) -> Tuple[EmbeddingsBatch, DeviceContext]:
+                              variance_noise: Optional[Tensor] = None, **kwargs) -> Tuple[EmbeddingsBatch, DeviceContext]:
         """batch.seqs (B, 1, D): the latest raw SONAR embedding of every active document.
         Returns the next embedding (B, 1, D) fp32 and the grown context handle.  `noise` (B, 1, D) or
-        (B, D) replaces the internal N(0, 1) draw."""
+        (B, D) replaces the internal N(0, 1) draw; `variance_noise` (n_steps, B, D) the per-step draws of
+        stochastic DDIM (ddim_eta > 0)."""
         assert context_state_bag is not None, "Expected a state_bag to incrementally encode the context"
         x = batch.seqs
         sess = self._session_for(context_state_bag, x.shape[0])
@@ -535,7 +580,13 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
         context_state_bag.increment_step_nr(x.shape[1])
         if noise is None:
             noise = self.sample_initial_noise_vectors(x.shape[0])
-        out = sess.denoise(noise.reshape(x.shape[0], -1), trace)
+        if self.ddim_eta > 0 and variance_noise is None:
+            # the reference draws these inside DDIMScheduler.step (randn_tensor, ddim.py:495-503), one per step
+            variance_noise = torch.randn(len(self.noise_scheduler.timesteps), x.shape[0], self.config.sonar_embed_dim,
+                                         device=self.device)
+        if variance_noise is not None:
+            variance_noise = variance_noise.reshape(len(self.noise_scheduler.timesteps), x.shape[0], -1)
+        out = sess.denoise(noise.reshape(x.shape[0], -1), trace, variance_noise if self.ddim_eta > 0 else None)
         return EmbeddingsBatch(out.unsqueeze(1), None), DeviceContext(sess, sess.context_len)
 
     # classifier-free guidance is selected by `prep_for_denoising`; both entry points share the kernel loop

@@ -126,18 +126,20 @@ class DDIMScheduler:
         return a_t, a_prev
 
     def _params(self, eta, epsilon_scaling, prediction_type, clip_noise=float("inf")) -> "_hip.DenoiseParams":
-        if self.config.thresholding:
-            raise NotImplementedError("dynamic thresholding is not implemented on the HIP path")
         return _hip.DenoiseParams(
             guidance_scale=1.0, guidance_rescale=0.0, ddim_eta=float(eta),
             epsilon_scaling=float(epsilon_scaling) if epsilon_scaling else 0.0,
             clip_noise=float(min(clip_noise, 3.0e38)), init_noise_sigma=float(self.init_noise_sigma),
             prediction_type=_hip.PRED[prediction_type or self.prediction_type],
-            clip_sample=int(self.config.clip_sample), clip_sample_range=float(self.config.clip_sample_range))
+            clip_sample=int(self.config.clip_sample), clip_sample_range=float(self.config.clip_sample_range),
+            thresholding=int(self.config.thresholding),
+            dynamic_thresholding_ratio=float(self.config.dynamic_thresholding_ratio),
+            sample_max_value=float(self.config.sample_max_value))
 
     # ---- per-call tensor API (GPU tensors, fp32) ---------------------------------------------------
     def step(self, model_output: Tensor, timestep, sample: Tensor, eta: float = 0.0,
-             prediction_type: Optional[str] = None, epsilon_scaling: Optional[float] = None) -> DDIMSchedulerOutput:
+             prediction_type: Optional[str] = None, epsilon_scaling: Optional[float] = None,
+             variance_noise: Optional[Tensor] = None, generator=None) -> DDIMSchedulerOutput:
         if self.num_inference_steps is None:
             raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
         _hip.require_gpu(sample, "sample")
@@ -148,8 +150,17 @@ class DDIMScheduler:
         prev, x0 = torch.empty_like(x), torch.empty_like(x)
         a_t, a_prev = self.alpha_pair(int(timestep))
         p = self._params(eta, epsilon_scaling, prediction_type)
+        vn = None
+        if eta > 0:                                   # reference ddim.py:487-506
+            if variance_noise is not None and generator is not None:
+                raise ValueError("Cannot pass both generator and variance_noise. Please make sure that either `generator` or"
+                                 " `variance_noise` stays `None`.")
+            if variance_noise is None:
+                variance_noise = torch.randn(x.shape, generator=generator, device=x.device, dtype=torch.float32)
+            vn = variance_noise.float().contiguous()
+            assert vn.numel() == x.numel(), "variance_noise must have the shape of the sample"
         _hip.check(_hip.lib.lcmhip_ddim_cfg_step(_hip.ptr(x), _hip.ptr(out), None, _hip.ptr(prev), _hip.ptr(x0),
-                                                 rows, dim, a_t, a_prev, p, _hip.stream_ptr(x.device)))
+                                                 rows, dim, a_t, a_prev, p, _hip.ptr(vn), _hip.stream_ptr(x.device)))
         return DDIMSchedulerOutput(prev, x0)
 
     def get_epsilon(self, model_output: Tensor, sample: Tensor, timestep) -> Tensor:

@@ -34,7 +34,10 @@ extern "C" {
 #define LCMHIP_ERR_STATE (-4)       /* call sequence error (e.g. denoise before set_schedule) */
 
 enum { LCMHIP_F32 = 0, LCMHIP_BF16 = 1 };
-enum { LCMHIP_NORM_LAYERNORM = 0, LCMHIP_NORM_RMS = 1 };
+/* lcm/nn/normalization.py:73-88: "standard" (LayerNorm, weight + bias), "rms" (RMSNorm, weight only), "fp32"
+ * (LayerNorm evaluated in fp32, weight only) and "unit" (LayerNorm without learnable parameters).  Every kind keeps
+ * its statistics in fp32 here, so "fp32" differs from "standard" only by the missing bias. */
+enum { LCMHIP_NORM_LAYERNORM = 0, LCMHIP_NORM_RMS = 1, LCMHIP_NORM_FP32 = 2, LCMHIP_NORM_UNIT = 3 };
 enum { LCMHIP_FFN_RELU = 0, LCMHIP_FFN_SWIGLU = 1 };
 enum { LCMHIP_POS_NONE = 0, LCMHIP_POS_LEARNED = 1, LCMHIP_POS_ROPE = 2 };
 enum { LCMHIP_PRED_SAMPLE = 0, LCMHIP_PRED_EPSILON = 1, LCMHIP_PRED_V = 2 };
@@ -83,13 +86,16 @@ typedef struct {
 typedef struct {
     float guidance_scale;
     float guidance_rescale;
-    float ddim_eta;            /* only 0 is implemented */
+    float ddim_eta;            /* > 0: stochastic DDIM (ddim.py:473-506); lcmhip_denoise then needs variance noise */
     float epsilon_scaling;     /* <= 0: disabled */
     float clip_noise;
     float init_noise_sigma;
     int32_t prediction_type;   /* LCMHIP_PRED_* configured for the model */
     int32_t clip_sample;       /* 0 / 1 */
     float clip_sample_range;
+    int32_t thresholding;      /* 0 / 1: dynamic thresholding of the predicted x0 (ddim.py:242-280); wins over clip_sample */
+    float dynamic_thresholding_ratio;
+    float sample_max_value;
 } lcmhip_denoise_params;
 
 /* One row of lcmhip_session_profile(): time spent in one kernel family while profiling was on. */
@@ -180,6 +186,13 @@ int lcmhip_base_forward(lcmhip_session* s, const float* x, int32_t n_tokens, int
  * is not NULL it receives prev_sample after every step, (n_steps, n_active, sonar_dim) fp32. */
 int lcmhip_denoise(lcmhip_session* s, const float* noise, float* out, float* latents_trace,
                    void* stream);
+
+/* lcmhip_denoise for a schedule with ddim_eta > 0 (DDIMScheduler.step, ddim.py:473-506: prev_sample +=
+ * eta * sqrt(variance_t) * variance_noise).  `variance_noise` (n_steps, n_active, sonar_dim) fp32 holds the N(0, 1)
+ * draw of every executed step (the reference draws it inside `step` with randn_tensor); it may be NULL when
+ * ddim_eta == 0, where this call equals lcmhip_denoise.  Runs launch by launch (no graph replay). */
+int lcmhip_denoise_stochastic(lcmhip_session* s, const float* noise, const float* variance_noise, float* out,
+                              float* latents_trace, void* stream);
 
 /* The denoiser over every position of every active document in one pass: the denoising half of
  * TwoTowerDiffusionLCModel.forward (builder.py:128-159, 193-213) = LCMDenoiser.forward with inference=False
@@ -287,11 +300,14 @@ int lcmhip_gemm_partial(const void* A, int32_t lda, const void* W, float* slab, 
  * (builder.py:463-488), DDIMScheduler.step (ddim.py:358-510, eta = 0) and the latent clip of
  * builder.py:452-454.  sample: (rows, dim) fp32 x_t; out_cond / out_uncond: (rows, dim) fp32
  * model outputs (out_uncond NULL: no guidance, `step` is applied to out_cond with the model's
- * prediction type); prev_sample, pred_x0: (rows, dim) fp32. */
+ * prediction type); prev_sample, pred_x0: (rows, dim) fp32.  `variance_noise` (rows, dim) fp32 is required when
+ * params->ddim_eta > 0 and ignored otherwise.  With params->thresholding the predicted x0 of every row is divided
+ * by s = clamp(quantile(|x0|, ratio), 1, sample_max_value) after clamping to [-s, s] (torch.quantile's linear
+ * interpolation). */
 int lcmhip_ddim_cfg_step(const float* sample, const float* out_cond, const float* out_uncond,
                          float* prev_sample, float* pred_x0, int32_t rows, int32_t dim,
                          float alpha_prod_t, float alpha_prod_t_prev,
-                         const lcmhip_denoise_params* params, void* stream);
+                         const lcmhip_denoise_params* params, const float* variance_noise, void* stream);
 
 /* Single-query-block attention over a per-document key/value cache: fairseq2 TorchSDPA as
  * called at attention.py:272-279 (scale 1/sqrt(128), -inf on masked keys).

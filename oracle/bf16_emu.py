@@ -97,13 +97,17 @@ def _lin(x: Tensor, sd: Dict[str, Tensor], prefix: str) -> Tensor:
 def _norm32(x: Tensor, sd: Dict[str, Tensor], prefix: str, kind: str, eps: float,
             shift: Optional[Tensor] = None, scale: Optional[Tensor] = None) -> Tensor:
     """Norm (+ adaLN modulation) entirely in fp32, rounded once (k_norm_modulate / k_norm_pending)."""
-    w = sd[prefix + ".weight"]
+    w = sd.get(prefix + ".weight")          # absent for the "unit" style
     if kind == "rms":
         y = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps) * w
-    else:
+    else:                                   # "standard" (weight + bias), "fp32" (weight), "unit" (neither)
         mean = x.mean(-1, keepdim=True)
         var = (x - mean).pow(2).mean(-1, keepdim=True)
-        y = (x - mean) * torch.rsqrt(var + eps) * w + sd[prefix + ".bias"]
+        y = (x - mean) * torch.rsqrt(var + eps)
+        if w is not None:
+            y = y * w
+        if kind == "standard":
+            y = y + sd[prefix + ".bias"]
     if scale is not None:
         y = y * (1.0 + scale) + shift
     return r16(y)
@@ -276,7 +280,7 @@ class OracleTwoTowerBf16(_Bf16Blocks, OracleTwoTower):
         return out
 
     def predict_next_sentence(self, x: Tensor, context: Tensor, cache: KVCache, noise: Tensor,
-                              trace: Optional[List] = None) -> Tuple[Tensor, Tensor]:
+                              trace: Optional[List] = None, variance_noise: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
         """builder.py:262-461 with the HIP path's data flow (cached cross K/V, constant unconditional cross-attention,
         folded self-attention); the generated embedding is rounded like the generator's bf16 sequence buffer."""
         sch = self.scheduler
@@ -288,14 +292,16 @@ class OracleTwoTowerBf16(_Bf16Blocks, OracleTwoTower):
         x0 = latents
         for si, t in enumerate(sch.timesteps.tolist()):
             guided = self.do_cfg and t != sch.num_train_steps - 1
+            vn = None if variance_noise is None else variance_noise[si].reshape(latents.shape)
             out = self._denoise_rows(r16(latents), si, kv, cfg_rows=guided)
             if guided:
                 inp = torch.cat([latents, latents], dim=0)
                 eps = self.apply_cfg(sch.get_epsilon(out, inp, t))
                 prev, x0 = sch.step(eps, t, latents, eta=self.ddim_eta, epsilon_scaling=self.epsilon_scaling,
-                                    prediction_type="epsilon")
+                                    prediction_type="epsilon", variance_noise=vn)
             else:
-                prev, x0 = sch.step(out, t, latents, eta=self.ddim_eta, epsilon_scaling=self.epsilon_scaling)
+                prev, x0 = sch.step(out, t, latents, eta=self.ddim_eta, epsilon_scaling=self.epsilon_scaling,
+                                    variance_noise=vn)
             latents = prev.clip(-self.clip_noise, self.clip_noise)
             if trace is not None:
                 trace.append((t, latents.clone(), x0.clone()))

@@ -58,9 +58,11 @@ class OracleGenerator:
     @torch.inference_mode()
     def __call__(self, seqs_in: Tensor, prompt_lens: Optional[Tensor] = None, max_gen_len: Optional[int] = None,
                  min_gen_len: Optional[int] = None, noise: Optional[Tensor] = None,
-                 trace: Optional[list] = None, temperature: float = 0.0) -> List[List[Hyp]]:
+                 trace: Optional[list] = None, temperature: float = 0.0,
+                 variance_noise: Optional[Tensor] = None) -> List[List[Hyp]]:
         """seqs_in (B,P,D) padded prompts; prompt_lens (B,) or None; noise (steps,B,D) consumed as
-        noise[step_nr - min_prompt_len, original document]."""
+        noise[step_nr - min_prompt_len, original document]; variance_noise (steps, diffusion steps, B, D) likewise
+        (stochastic DDIM only)."""
         opt, model = self.options, self.model
         self.temperature = temperature if temperature != 0.0 else opt.lcm_temperature   # lcm/generator.py:174-179
         B, P_max, D = seqs_in.shape
@@ -106,8 +108,11 @@ class OracleGenerator:
                                     temperature=self.temperature)
                 cache.increment_step_nr()
             else:
+                vn = None
+                if variance_noise is not None:
+                    vn = variance_noise[step_nr - P_min].index_select(1, sample_idx).unsqueeze(2)
                 out, context = model.predict_next_sentence(seqs[:, step_nr - 1:step_nr], context, cache, nz,
-                                                           trace=trace)
+                                                           trace=trace, variance_noise=vn)
             last = out[:, -1]
 
             # ---- finalize_step (generator.py:305-423)

@@ -11,6 +11,7 @@ CausalAttentionMaskFactory, FullAttentionState), which are restated from their p
 behaviour because fairseq2 is not installable here.
 """
 
+import dataclasses
 import math
 from typing import Dict, List, Optional, Tuple
 
@@ -30,8 +31,13 @@ def linear(x: Tensor, sd: Dict[str, Tensor], prefix: str) -> Tensor:
 
 def norm(x: Tensor, sd: Dict[str, Tensor], prefix: str, kind: str, eps: float) -> Tensor:
     """lcm/nn/normalization.py:73-88.  rms = fairseq2 RMSNorm(bias=False): normalise in fp32,
-    cast back, then multiply by weight; standard = F.layer_norm with weight and bias."""
+    cast back, then multiply by weight; standard = F.layer_norm with weight and bias; fp32 = layer_norm
+    evaluated in fp32 with a weight and no bias (:17-33, 46-53); unit = layer_norm without parameters (:56-70)."""
+    if kind == "unit":
+        return F.layer_norm(x, (x.shape[-1],), None, None, eps)
     w = sd[prefix + ".weight"]
+    if kind == "fp32":
+        return F.layer_norm(x.float(), (x.shape[-1],), w.float(), None, eps).type_as(x)
     if kind == "rms":
         xf = x.float()
         y = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
@@ -134,7 +140,7 @@ class OracleTwoTower:
         self.cfg = cfg
         self.sd = sd
         self.model_dim = cfg.model_dim
-        self.scheduler = DDIMSchedule(cfg.scheduler)
+        self.scheduler = DDIMSchedule(dataclasses.replace(cfg.scheduler))   # own copy: prep_for_denoising edits it
         # Tests with long contexts set this: the cross-attention k/v projections of the context are then computed
         # once per predict_next_sentence call instead of at every diffusion step (the context does not change
         # between the steps of one call, so the values are the same; the reference, and the CPU baseline timing,
@@ -142,11 +148,17 @@ class OracleTwoTower:
         self.memoize_cross_kv = False
         self._kv_memo = None
 
-    # -- SONAR normalizer (lcm/models/sonar_normalizer/builder.py:121-137; base arch: no clip, no fft)
+    # -- SONAR normalizer (lcm/models/sonar_normalizer/builder.py:121-137; clipping when the state dict holds
+    #    clip_min / clip_max, i.e. the "clipping" arch; no fft)
     def normalize(self, x: Tensor) -> Tensor:
-        return (x - self.sd["sonar_normalizer.center"]) / self.sd["sonar_normalizer.scale"]
+        y = (x - self.sd["sonar_normalizer.center"]) / self.sd["sonar_normalizer.scale"]
+        if "sonar_normalizer.clip_min" in self.sd:
+            y = torch.clamp(y, min=self.sd["sonar_normalizer.clip_min"], max=self.sd["sonar_normalizer.clip_max"])
+        return y
 
     def denormalize(self, x: Tensor) -> Tensor:
+        if "sonar_normalizer.clip_min" in self.sd:
+            x = torch.clamp(x, min=self.sd["sonar_normalizer.clip_min"], max=self.sd["sonar_normalizer.clip_max"])
         return x * self.sd["sonar_normalizer.scale"] + self.sd["sonar_normalizer.center"]
 
     # -- attention / ffn blocks
@@ -290,10 +302,13 @@ class OracleTwoTower:
         return factor * g
 
     def predict_next_sentence(self, x: Tensor, context: Tensor, cache: KVCache, noise: Tensor,
-                              trace: Optional[List] = None) -> Tuple[Tensor, Tensor]:
+                              trace: Optional[List] = None, variance_noise: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
         """x (B,1,D) raw SONAR embeddings, context (B,t,d) -> (next embedding (B,1,D), new context).
         builder.py:262-338 (no guidance) and :340-461 (classifier-free guidance).  `noise` (B,1,D)
-        replaces the in-function torch.randn; `trace`, if given, collects per-step latents."""
+        replaces the in-function torch.randn; `variance_noise` (steps,B,1,D) the per-step draws of DDIMScheduler.step
+        when eta > 0 (ddim.py:495-503); `trace`, if given, collects per-step latents."""
+        def vnoise(si):
+            return None if variance_noise is None else variance_noise[si].reshape(noise.shape)
         sch = self.scheduler
         new_ctx = self.encode(self.normalize(x), cache)
         cache.increment_step_nr(1)
@@ -302,10 +317,11 @@ class OracleTwoTower:
         B = x.shape[0]
         self._kv_memo = {} if self.memoize_cross_kv else None      # valid for this call's (fixed) context only
         if not self.do_cfg:
-            for t in sch.timesteps.tolist():
+            for si, t in enumerate(sch.timesteps.tolist()):
                 ts = torch.full((B, 1), t, dtype=torch.long)
                 out = self.denoise(latents, ts, context)
-                prev, x0 = sch.step(out, t, latents, eta=self.ddim_eta, epsilon_scaling=self.epsilon_scaling)
+                prev, x0 = sch.step(out, t, latents, eta=self.ddim_eta, epsilon_scaling=self.epsilon_scaling,
+                                    variance_noise=vnoise(si))
                 latents = prev.clip(-self.clip_noise, self.clip_noise)
                 if trace is not None:
                     trace.append((t, latents.clone(), x0.clone()))
@@ -315,19 +331,20 @@ class OracleTwoTower:
         t_len = context.shape[1]
         ctx2 = torch.cat((context, torch.zeros_like(context)), dim=0)                 # :378-381
         lens2 = torch.cat((torch.full((B,), t_len), torch.zeros(B, dtype=torch.long)))
-        for t in sch.timesteps.tolist():
+        for si, t in enumerate(sch.timesteps.tolist()):
             is_max = t == sch.num_train_steps - 1                                     # :385-387
             inp = torch.cat([latents, latents], dim=0)
             ts = torch.full((2 * B, 1), t, dtype=torch.long)
             out = self.denoise(inp, ts, ctx2, lens2)
             if is_max:                                                                # :404-419
                 prev, x0 = sch.step(out.chunk(2)[0], t, latents, eta=self.ddim_eta,
-                                    epsilon_scaling=self.epsilon_scaling)
+                                    epsilon_scaling=self.epsilon_scaling, variance_noise=vnoise(si))
             else:                                                                     # :420-449
                 eps = sch.get_epsilon(out, inp, t)
                 eps = self.apply_cfg(eps)
                 prev, x0 = sch.step(eps, t, latents, eta=self.ddim_eta,
-                                    epsilon_scaling=self.epsilon_scaling, prediction_type="epsilon")
+                                    epsilon_scaling=self.epsilon_scaling, prediction_type="epsilon",
+                                    variance_noise=vnoise(si))
             latents = prev.clip(-self.clip_noise, self.clip_noise)
             if trace is not None:
                 trace.append((t, latents.clone(), x0.clone()))

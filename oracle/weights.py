@@ -50,7 +50,8 @@ def _tower_shapes(prefix: str, d: int, tc: TowerConfig, cross: bool, modulator: 
         p = f"{prefix}.layers.{i}"
         norms = ["self_attn_layer_norm"] + (["cross_attention_layer_norm"] if cross else []) + ["ffn_layer_norm"]
         for n in norms:
-            yield f"{p}.{n}.weight", (d,), "norm_w"
+            if tc.norm != "unit":            # lcm/nn/normalization.py:56-70: no learnable parameters
+                yield f"{p}.{n}.weight", (d,), "norm_w"
             if tc.norm == "standard":
                 yield f"{p}.{n}.bias", (d,), "norm_b"
         for attn in ["self_attn"] + (["cross_attention"] if cross else []):
@@ -71,7 +72,8 @@ def _tower_shapes(prefix: str, d: int, tc: TowerConfig, cross: bool, modulator: 
         if modulator:
             yield f"{p}.modulator.fc.weight", (9 * d, d), "mod_w"
             yield f"{p}.modulator.fc.bias", (9 * d,), "mod_b"
-    yield f"{prefix}.layer_norm.weight", (d,), "norm_w"
+    if tc.norm != "unit":
+        yield f"{prefix}.layer_norm.weight", (d,), "norm_w"
     if tc.norm == "standard":
         yield f"{prefix}.layer_norm.bias", (d,), "norm_b"
 

@@ -43,8 +43,8 @@ for dim in (1024, 2048):
            rows * dim * (4 + 2), f"rmsnorm+modulate d={dim} f32->bf16")
 x = torch.randn(ROWS, D, device=dev); oc = torch.randn(ROWS, D, device=dev); ou = torch.randn(ROWS, D, device=dev)
 prev = torch.empty_like(x); x0 = torch.empty_like(x)
-par = _hip.DenoiseParams(3.0, 0.7, 0.0, 0.0, 100.0, 0.6, 0, 0, 1.0)
+par = _hip.DenoiseParams(3.0, 0.7, 0.0, 0.0, 100.0, 0.6, 0, 0, 1.0, 0, 0.995, 1.0)
 timeit(lambda: _hip.check(_hip.lib.lcmhip_ddim_cfg_step(_hip.ptr(x), _hip.ptr(oc), _hip.ptr(ou), _hip.ptr(prev), _hip.ptr(x0), ROWS, D,
-                                                         0.5, 0.6, C.byref(par), st)),
+                                                         0.5, 0.6, C.byref(par), None, st)),
        5 * ROWS * D * 4, "ddim+cfg step f32 (3 in, 2 out)")
 print(json.dumps({"rows": ROWS, "peak_GBps": PEAK, "kernels": res}))

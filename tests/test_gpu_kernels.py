@@ -225,36 +225,51 @@ def test_gemm_rejects_bad_shapes(hip):
         _gemm(hip, A, W, None, None, None, None, out, hip.EPI_STORE)
 
 
-@pytest.mark.parametrize("mode", ["plain_sample", "plain_epsilon", "cfg"])
-def test_ddim_cfg_step(hip, mode):
+@pytest.mark.parametrize("thresholding", [False, True])
+@pytest.mark.parametrize("eta", [0.0, 0.6])
+@pytest.mark.parametrize("mode", ["plain_sample", "plain_epsilon", "plain_v", "cfg"])
+def test_ddim_cfg_step(hip, mode, eta, thresholding):
+    """One fused update against the oracle's scheduler: every prediction type, guidance, stochastic DDIM
+    (ddim.py:473-506, host-supplied variance noise) and dynamic thresholding (ddim.py:242-280, torch.quantile)."""
     import oracle
     from oracle.archs import SchedulerConfig
     torch.manual_seed(3)
     rows, dim = 5, 1024
-    sch = oracle.DDIMSchedule(SchedulerConfig(num_train_steps=100))
+    ptype = {"plain_sample": "sample", "plain_epsilon": "epsilon", "plain_v": "v_prediction", "cfg": "sample"}[mode]
+    cfg = SchedulerConfig(num_train_steps=100, prediction_type=ptype, thresholding=thresholding,
+                          dynamic_thresholding_ratio=0.9, sample_max_value=1.7)
+    sch = oracle.DDIMSchedule(cfg)
     sch.set_timesteps(40)
     t = 57
     x = torch.randn(rows, 1, dim) * 0.8
     oc, ou = torch.randn(rows, 1, dim), torch.randn(rows, 1, dim)
+    oc[1] *= 0.3           # a row whose quantile stays below 1 (s clamps to 1) ...
+    oc[2] *= 3.0           # ... and one whose quantile exceeds sample_max_value
+    vn = torch.randn(rows, 1, dim)
     a_t, a_prev = sch._alphas(t)
-    p = hip.DenoiseParams(guidance_scale=3.0, guidance_rescale=0.7, ddim_eta=0.0, epsilon_scaling=0.0, clip_noise=1.5,
-                          init_noise_sigma=1.0, prediction_type=hip.PRED["epsilon" if mode == "plain_epsilon" else "sample"],
-                          clip_sample=0, clip_sample_range=1.0)
+    p = hip.DenoiseParams(guidance_scale=3.0, guidance_rescale=0.7, ddim_eta=eta, epsilon_scaling=1.1, clip_noise=1.5,
+                          init_noise_sigma=1.0, prediction_type=hip.PRED[ptype], clip_sample=0, clip_sample_range=1.0,
+                          thresholding=int(thresholding), dynamic_thresholding_ratio=0.9, sample_max_value=1.7)
+    kw = dict(eta=eta, epsilon_scaling=1.1, variance_noise=vn if eta > 0 else None)
     if mode == "cfg":
         class M:  # the oracle's guidance needs only these attributes
             guidance_scale, guidance_rescale = 3.0, 0.7
         eps = sch.get_epsilon(torch.cat([oc, ou]), torch.cat([x, x]), t)
         eps = oracle.OracleTwoTower.apply_cfg(M, eps)
-        prev, x0 = sch.step(eps, t, x, prediction_type="epsilon")
+        prev, x0 = sch.step(eps, t, x, prediction_type="epsilon", **kw)
     else:
-        prev, x0 = sch.step(oc, t, x, prediction_type="epsilon" if mode == "plain_epsilon" else "sample")
+        prev, x0 = sch.step(oc, t, x, prediction_type=ptype, **kw)
     prev = prev.clip(-1.5, 1.5)
     xg, ocg, oug = x.reshape(rows, dim).cuda(), oc.reshape(rows, dim).cuda(), ou.reshape(rows, dim).cuda()
+    vng = vn.reshape(rows, dim).cuda() if eta > 0 else None
     pg, zg = torch.empty_like(xg), torch.empty_like(xg)
     hip.check(hip.lib.lcmhip_ddim_cfg_step(hip.ptr(xg), hip.ptr(ocg), hip.ptr(oug) if mode == "cfg" else None, hip.ptr(pg),
-                                           hip.ptr(zg), rows, dim, float(a_t), float(a_prev), C.byref(p), _st(hip)))
+                                           hip.ptr(zg), rows, dim, float(a_t), float(a_prev), C.byref(p), hip.ptr(vng), _st(hip)))
     assert (pg.cpu() - prev.reshape(rows, dim)).abs().max() <= 2e-5
     assert (zg.cpu() - x0.reshape(rows, dim)).abs().max() <= 2e-5 * max(1.0, float(x0.abs().max()))
+    if eta > 0:     # missing variance noise is an error, not a silent deterministic step
+        assert hip.lib.lcmhip_ddim_cfg_step(hip.ptr(xg), hip.ptr(ocg), None, hip.ptr(pg), hip.ptr(zg), rows, dim, float(a_t),
+                                            float(a_prev), C.byref(p), None, _st(hip)) == -1
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -124,3 +124,34 @@ def test_base_lcm_registry_and_no_cpu_fallback():
     assert (t.model_dim, t.lcm.num_layers, t.sonar_normalizer_name, t.frontend.pre_linear_bias) == (1024, 2, None, True)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         create_base_lcm_model(t, device="cpu")
+
+
+def test_norm_styles_and_clipping_normalizer_shape_the_parameter_table():
+    """Without a GPU: the `unit` norm style has no parameters, `fp32` and `rms` a weight only, `standard` weight and
+    bias (lcm/nn/normalization.py:36-88); a model that names a normalizer card of the `clipping` arch carries
+    clip_min / clip_max (lcm/models/sonar_normalizer/builder.py:111-117), FFT variants are refused."""
+    from lcm.models.sonar_normalizer.builder import SonarNormalizerConfig
+    from lcm.models.two_tower_diffusion_lcm.builder import normalizer_config_for, parameter_spec
+    from lcm.utils.card_utils import register_card
+    from parity_utils import mini_config
+    cfg = mini_config()
+    cfg.context_encoder.layer_normalization_style = "unit"
+    cfg.denoiser.layer_normalization_style = "fp32"
+    names = {n for n, _, _ in parameter_spec(cfg)}
+    assert not any(n.startswith("context_encoder") and "layer_norm" in n for n in names)
+    assert "denoiser.layers.0.ffn_layer_norm.weight" in names and "denoiser.layers.0.ffn_layer_norm.bias" not in names
+    ocfg = oracle.get_arch("mini_two_tower_diffusion_lcm")
+    ocfg.context.norm, ocfg.denoiser.norm = "unit", "fp32"
+    assert names == {n for n, _, _ in state_dict_spec(ocfg)}
+    register_card({"name": "host_test_clip_normalizer", "model_family": "sonar_normalizer", "model_arch": "clipping",
+                   "checkpoint": None})
+    ncfg = normalizer_config_for("host_test_clip_normalizer", 1024)
+    assert ncfg.clip_proba is not None
+    clip_names = {n for n, _, _ in parameter_spec(mini_config(), ncfg)}
+    assert {"sonar_normalizer.clip_min", "sonar_normalizer.clip_max"} <= clip_names
+    assert normalizer_config_for("dummy_sonar_normalizer", 1024).clip_proba is None
+    assert normalizer_config_for(None, 1024) == SonarNormalizerConfig(dim=1024)
+    register_card({"name": "host_test_fft_normalizer", "model_family": "sonar_normalizer", "model_arch": "base_fft",
+                   "checkpoint": None})
+    with pytest.raises(NotImplementedError):
+        normalizer_config_for("host_test_fft_normalizer", 1024)
