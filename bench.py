@@ -209,15 +209,19 @@ def whole_step_roofline(model, batch, prompt_len, gen_len, seconds_per_job):
     d, D, F, L = c.model_dim, c.sonar_embed_dim, c.denoiser.allocated_ffn_dim(), c.denoiser.num_layers
     es = 2 if model.dtype == torch.bfloat16 else 4
     n_ffn = 3 if c.denoiser.use_swiglu else 2
-    weights = (2 * D * d + L * (d * d + 2 * d * d + n_ffn * d * F)) * es          # folded W_ov, cross q / o, FFN
+    # every GEMM weight a denoiser row passes through: self-attention q, k, v, o + cross-attention q, o + FFN ...
+    weights = (2 * D * d + L * (4 * d * d + 2 * d * d + n_ffn * d * F)) * es
+    # ... of which this build streams less: the one-position self-attention is folded into a single d x d matrix
+    streamed = (2 * D * d + L * (d * d + 2 * d * d + n_ffn * d * F)) * es
     mean_keys = prompt_len + (gen_len - 1) / 2.0 + 1.0                              # zero slot + context
     kv = batch * L * 2 * mean_keys * d * es
     steps = len(model.noise_scheduler.timesteps)
     ms = 1e3 * seconds_per_job / (gen_len * steps)
     achieved = (weights + kv) / ms / 1e6
     return dict(bytes_per_diffusion_step=round(weights + kv), weight_bytes=round(weights), kv_bytes=round(kv),
-                ms_per_diffusion_step=round(ms, 4), achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                frac=round(achieved / HBM_PEAK_GBS, 4))
+                streamed_weight_bytes=round(streamed), ms_per_diffusion_step=round(ms, 4), achieved=round(achieved, 1),
+                peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
+                streamed_frac=round((streamed + kv) / ms / 1e6 / HBM_PEAK_GBS, 4))
 
 
 def check_timed_output(model, gen, seqs, noise, prompt_len, gen_len, device, doc=0):
@@ -247,7 +251,11 @@ _PMC_SYMBOL = {"den.ffn_in": "k_gemm_dma<3, 4,", "den.norm_mod": "k_norm_modulat
 def pmc_traffic(family):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (FETCH_SIZE doubled for gfx950 + WRITE_SIZE; counters cannot be read from inside this process)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_hbm_traffic.json")
+    import glob
+    prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    found = sorted(glob.glob(os.path.join(prof, "r*_pmc_hbm_traffic.json")))      # the latest round's passes
+    path = found[-1] if found else os.path.join(prof, "r1_pmc_hbm_traffic.json")
+    rnd = os.path.basename(path).split("_")[0]
     key = _PMC_SYMBOL.get(family)
     if key is None or not os.path.exists(path):
         return {"traffic": None}
@@ -255,11 +263,11 @@ def pmc_traffic(family):
     for row in json.load(open(path))["kernels"]:
         if key in row["kernel"]:
             out = {"traffic": row["hbm_bytes_per_launch_corrected"],
-                   "traffic_source": "profiles/r1_pmc_hbm_traffic.json (separate rocprofv3 --pmc passes)"}
+                   "traffic_source": f"profiles/{rnd}_pmc_hbm_traffic.json (separate rocprofv3 --pmc passes)"}
             break
     # cross-reference: the same kernel's average duration in the committed rocprofv3 --kernel-trace --stats summary
     # (pure kernel time; the event pair used above also spans the launch boundary, about 2 us)
-    stats = os.path.join(os.path.dirname(path), "r1_bench_kernel_stats.csv")
+    stats = os.path.join(os.path.dirname(path), f"{rnd}_bench_kernel_stats.csv")
     if os.path.exists(stats):
         import csv
         for r in csv.DictReader(open(stats, newline="")):
