@@ -265,6 +265,8 @@ __host__ __device__ inline size_t kv_cache_offset(int r, int n, int cap, int d) 
     const int slot = r / cap, pos = r % cap;
     return (((size_t)slot * (d >> 7) + (n >> 7)) * cap + pos) * 128 + (n & 127);
 }
+int launch_finalize_step(const float* new_emb, void* seqs, int dtype, const int32_t* doc_rows, const int32_t* prompt_lens,
+                         int n_active, int step, int total_len, int dim, const float* eos, float* cos_out, hipStream_t st);
 int launch_silu_cast(const float* x, void* y, int64_t n, int dtype, hipStream_t st);
 int launch_cast(const float* x, void* y, int64_t n, int dtype, hipStream_t st);
 int launch_broadcast_rows(const float* src, float* dst, int rows, int d, hipStream_t st);

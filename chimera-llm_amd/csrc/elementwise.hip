@@ -799,6 +799,71 @@ int launch_init_latents(const float* noise, float* lat, int64_t n, float sigma, 
     return LCMHIP_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// End of a generation step (finalize_step of the generators): active row r belongs to document doc = doc_rows[r].
+// A document still inside its prompt (prompt_lens[doc] > step) keeps the prompt embedding already stored at
+// seqs[doc][step]; every other row stores its new embedding there (cast to the buffer's dtype).  Both cosines of
+// the stopping rules are taken on the fp32 value: against the EOS vector and against the document's previous
+// sentence seqs[doc][step - 1].  cos_out: (n_active, 2).  One workgroup per row, dim <= 4096.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_finalize_step(const float* __restrict__ new_emb, T* __restrict__ seqs,
+                                                       const int32_t* __restrict__ doc_rows,
+                                                       const int32_t* __restrict__ prompt_lens, int step, int total_len,
+                                                       int dim, const float* __restrict__ eos, float* __restrict__ cos_out) {
+    __shared__ float red[4];
+    const int r = blockIdx.x;
+    const int doc = doc_rows ? doc_rows[r] : r;
+    const bool in_prompt = prompt_lens != nullptr && prompt_lens[doc] > step;      // uniform per workgroup
+    T* cur = seqs + ((size_t)doc * total_len + step) * dim;
+    const T* prev = step > 0 ? cur - dim : nullptr;
+    float dot_e = 0.f, dot_p = 0.f, nv = 0.f, ne = 0.f, np = 0.f;
+    for (int c = threadIdx.x * 8; c < dim; c += 256 * 8) {
+        float v[8];
+        if (in_prompt) {
+            load8<T>(cur + c, v);
+        } else {
+            load8<float>(new_emb + (size_t)r * dim + c, v);
+            store8<T>(cur + c, v);
+        }
+        float e[8], p[8];
+        if (eos != nullptr) load8<float>(eos + c, e);
+        if (prev != nullptr) load8<T>(prev + c, p);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            nv += v[j] * v[j];
+            if (eos != nullptr) { dot_e += e[j] * v[j]; ne += e[j] * e[j]; }
+            if (prev != nullptr) { dot_p += p[j] * v[j]; np += p[j] * p[j]; }
+        }
+    }
+    nv = block_sum<4>(nv, red);
+    dot_e = block_sum<4>(dot_e, red); ne = block_sum<4>(ne, red);
+    dot_p = block_sum<4>(dot_p, red); np = block_sum<4>(np, red);
+    if (threadIdx.x == 0) {
+        const float eps = 1e-8f;     // torch.nn.functional.cosine_similarity: each norm is clamped from below
+        const float nvs = fmaxf(sqrtf(nv), eps);
+        cos_out[2 * r] = eos != nullptr ? dot_e / (nvs * fmaxf(sqrtf(ne), eps)) : 0.f;
+        cos_out[2 * r + 1] = prev != nullptr ? dot_p / (nvs * fmaxf(sqrtf(np), eps)) : 0.f;
+    }
+}
+
+int launch_finalize_step(const float* new_emb, void* seqs, int dtype, const int32_t* doc_rows, const int32_t* prompt_lens,
+                         int n_active, int step, int total_len, int dim, const float* eos, float* cos_out, hipStream_t st) {
+    LCM_REQUIRE(dim % 8 == 0 && dim <= 4096, "finalize_step: dim must be a multiple of 8, at most 4096");
+    LCM_REQUIRE(step >= 0 && step < total_len, "finalize_step: step outside the sequence buffer");
+    if (n_active <= 0) return LCMHIP_OK;
+    if (dtype == LCMHIP_BF16)
+        hipLaunchKernelGGL((k_finalize_step<bf16_t>), dim3(n_active), dim3(256), 0, st, new_emb, (bf16_t*)seqs, doc_rows,
+                           prompt_lens, step, total_len, dim, eos, cos_out);
+    else if (dtype == LCMHIP_F32)
+        hipLaunchKernelGGL((k_finalize_step<float>), dim3(n_active), dim3(256), 0, st, new_emb, (float*)seqs, doc_rows,
+                           prompt_lens, step, total_len, dim, eos, cos_out);
+    else
+        return fail(LCMHIP_ERR_INVALID, "finalize_step: unknown dtype");
+    LCM_HIP_CHECK(hipGetLastError());
+    return LCMHIP_OK;
+}
+
 // q/k/v: (rows, d).  Rotates consecutive pairs (2i, 2i+1) of every 128-wide head of q (in place) and
 // k by the angle table row `positions[r]`, and scatters k, v to cache row `cache_rows[r]`.
 template <typename T>

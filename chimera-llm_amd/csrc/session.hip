@@ -1323,6 +1323,14 @@ int lcmhip_ddim_cfg_step(const float* sample, const float* out_cond, const float
     return launch_ddim_step(sample, out_cond, out_uncond, prev_sample, pred_x0, rows, dim, sc, static_cast<hipStream_t>(stream), &io);
 }
 
+int lcmhip_finalize_step(const float* new_emb, void* seqs, int32_t seqs_dtype, const int32_t* doc_rows,
+                         const int32_t* prompt_lens, int32_t n_active, int32_t step, int32_t total_len, int32_t dim,
+                         const float* eos_vec, float* cos_out, void* stream) {
+    LCM_REQUIRE(new_emb && seqs && cos_out, "finalize_step: null argument");
+    return launch_finalize_step(new_emb, seqs, seqs_dtype, doc_rows, prompt_lens, n_active, step, total_len, dim, eos_vec,
+                                cos_out, static_cast<hipStream_t>(stream));
+}
+
 int lcmhip_attention(const void* q, const void* k_cache, const void* v_cache, const int32_t* slot_map, void* out,
                      int32_t n_docs, int32_t s, int32_t n_heads, int32_t cap, int32_t base_keys, int32_t causal,
                      int32_t dtype, void* stream) {

@@ -22,6 +22,7 @@ from typing import List, Optional
 import torch
 from torch import Tensor
 
+from lcm import _hip
 from lcm.datasets.batch import EmbeddingsBatch
 from lcm.inference.output import GenerationCounters, Hypothesis, SequenceGeneratorOutput
 from lcm.nn.incremental_state import LCMIncrementalStateBag
@@ -150,8 +151,12 @@ class LCMGenerator:
         lengths = [-1] * B
         active = list(range(B))                       # documents still generating, ascending
         active_t = torch.arange(B, device=device)
-        eos = self.eos_vec.to(device).float() if (self.eos_threshold is not None and self.eos_vec is not None) else None
+        eos = self.eos_vec.to(device).float().contiguous() if (self.eos_threshold is not None and self.eos_vec is not None) else None
         rep_thr = opt.stop_on_repetition_cosine_threshold
+        seq_code = _hip.dtype_code(self.seqs.dtype)
+        cos_buf = torch.zeros((B, 2), device=device, dtype=torch.float32)
+        prompt_lens_dev = None if prompt_lens is None else torch.tensor(prompt_lens, device=device, dtype=torch.int32)
+        active_i32 = active_t.to(torch.int32)
 
         try:
             # ---- prefill: every prompt position but the last one common to all documents
@@ -177,23 +182,24 @@ class LCMGenerator:
                     self._variance_step = vn if everyone else vn[:, active_t]
                 new = self._predict(prev, nz, active_t, everyone)            # (n_act, D) fp32
 
-                # ---- stopping rules (host-side unless an EOS / repetition test needs the embeddings)
+                # ---- finalize_step: one kernel keeps the prompt embedding of rows still inside their prompt, stores
+                # every other row's new sentence into the sequence buffer and takes the two cosines of the stopping
+                # rules; the host reads them (the only sync of the step) only when a rule needs them
                 in_prompt = [False] * n_act
-                if step < P_max:
-                    assert prompt_mask is not None
+                if step < P_max and prompt_lens is not None:
                     in_prompt = [prompt_lens[d] > step for d in active]
-                    if any(in_prompt):
-                        m = prompt_mask[:, step] if everyone else prompt_mask[active_t, step]
-                        src = self.seqs[:, step] if everyone else self.seqs[active_t, step]
-                        new = torch.where(m.unsqueeze(-1), src.float(), new)
+                need_cos = eos is not None or (rep_thr is not None and step > 0)
+                new32 = new.float().contiguous()
+                _hip.check(_hip.lib.lcmhip_finalize_step(
+                    _hip.ptr(new32), _hip.ptr(self.seqs), seq_code, None if everyone else _hip.ptr(active_i32),
+                    _hip.ptr(prompt_lens_dev) if step < P_max else None, n_act, step, total, D, _hip.ptr(eos),
+                    _hip.ptr(cos_buf), _hip.stream_ptr(device)))
                 stop = [False] * n_act
-                if eos is not None or (rep_thr is not None and step > 0):
-                    hit = torch.zeros(n_act, dtype=torch.bool, device=device)
-                    if eos is not None:
-                        hit |= torch.nn.functional.cosine_similarity(eos, new).ge(self.eos_threshold)
-                    if rep_thr is not None and step > 0:
-                        hit |= torch.nn.functional.cosine_similarity(prev[:, 0].float(), new).ge(rep_thr)
-                    stop = hit.tolist()                                      # the only sync of the step
+                if need_cos:
+                    cos = cos_buf[:n_act].tolist()
+                    for r in range(n_act):
+                        stop[r] = ((eos is not None and cos[r][0] >= self.eos_threshold)
+                                   or (rep_thr is not None and step > 0 and cos[r][1] >= rep_thr))
                 finished_now = []
                 for r, d in enumerate(active):
                     plen = prompt_lens[d] if prompt_lens is not None else P_max
@@ -201,11 +207,6 @@ class LCMGenerator:
                     if eos_stop or (step - plen + 1) >= max_gen_len:
                         lengths[d] = step + 1
                         finished_now.append((r, d, eos_stop))
-
-                if everyone:
-                    self.seqs[:, step] = new.to(self.seqs.dtype)
-                else:
-                    self.seqs[active_t, step] = new.to(self.seqs.dtype)
 
                 if finished_now:
                     for _, d, eos_stop in finished_now:
@@ -219,6 +220,7 @@ class LCMGenerator:
                         break
                     active = [active[r] for r in keep]
                     active_t = torch.tensor(active, device=device)
+                    active_i32 = active_t.to(torch.int32)
                     self.reorder_state(keep)
         finally:
             self._release()

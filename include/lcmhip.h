@@ -309,6 +309,18 @@ int lcmhip_ddim_cfg_step(const float* sample, const float* out_cond, const float
                          float alpha_prod_t, float alpha_prod_t_prev,
                          const lcmhip_denoise_params* params, const float* variance_noise, void* stream);
 
+/* The tensor work of finalize_step (lcm/inference/two_tower_diffusion_lcm/generator.py:305-351, 403; the base
+ * generator's lcm/inference/lcm/generator.py:288-330 is the same): for active row r of document doc_rows[r] (NULL:
+ * doc = r), a document still inside its prompt (prompt_lens[doc] > step; prompt_lens NULL: none) keeps the prompt
+ * embedding already stored at seqs[doc][step] (generator.py:322-328), every other row stores new_emb[r] there in the
+ * buffer's dtype (:403).  cos_out (n_active, 2) fp32 receives the two cosines of the stopping rules for the value
+ * kept: against eos_vec (:331-336; 0 when eos_vec is NULL) and against the previous sentence seqs[doc][step - 1]
+ * (:339-351; 0 at step 0).  new_emb (n_active, dim) fp32; seqs (n_docs, total_len, dim) in seqs_dtype;
+ * doc_rows, prompt_lens: int32 device arrays; eos_vec (dim) fp32.  The thresholds are applied by the host. */
+int lcmhip_finalize_step(const float* new_emb, void* seqs, int32_t seqs_dtype, const int32_t* doc_rows,
+                         const int32_t* prompt_lens, int32_t n_active, int32_t step, int32_t total_len, int32_t dim,
+                         const float* eos_vec, float* cos_out, void* stream);
+
 /* Single-query-block attention over a per-document key/value cache: fairseq2 TorchSDPA as
  * called at attention.py:272-279 (scale 1/sqrt(128), -inf on masked keys).
  * q: (n_docs * s, H * 128) in `dtype`; k_cache / v_cache: (n_slots, H, cap, 128) -- the keys of one

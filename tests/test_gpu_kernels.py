@@ -353,3 +353,41 @@ def test_gemm_partial_residual_norm(hip, dtype, mode, kind, N):
         ref_y = ref_y * (1 + scale.double().cpu()) + shift.double().cpu()
     tol_y = 1e-4 if dtype == torch.float32 else 4e-2
     assert (y[:rows_norm].double().cpu() - ref_y).abs().max() <= tol_y
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_finalize_step(hip, dtype):
+    """The tensor work of the generators' finalize_step against plain torch: prompt rows keep their embedding, other
+    rows are stored in the buffer's dtype, both stopping-rule cosines are torch.nn.functional.cosine_similarity."""
+    torch.manual_seed(11)
+    n_docs, total, dim, step = 7, 6, 1024, 3
+    seqs = (torch.randn(n_docs, total, dim, device="cuda") * 0.02).to(dtype)
+    before = seqs.clone()
+    docs = torch.tensor([0, 2, 3, 6], device="cuda", dtype=torch.int32)
+    plens = torch.tensor([2, 9, 5, 3, 9, 9, 4], device="cuda", dtype=torch.int32)        # documents 2 and 6 still in their prompt
+    new = torch.randn(4, dim, device="cuda") * 0.02
+    new[1] = before[2, step - 1].float() * 1.5                                             # a repetition (cosine 1) ...
+    eos = new[0].clone() * 3.0                                                             # ... and an EOS hit for row 0
+    cos = torch.full((4, 2), -7.0, device="cuda")
+    hip.check(hip.lib.lcmhip_finalize_step(hip.ptr(new), hip.ptr(seqs), hip.dtype_code(dtype), hip.ptr(docs), hip.ptr(plens),
+                                           4, step, total, dim, hip.ptr(eos), hip.ptr(cos), _st(hip)))
+    torch.cuda.synchronize()
+    kept = torch.stack([before[2, step].float() if d in (2, 6) and False else new[r] for r, d in enumerate(docs.tolist())])
+    kept[1], kept[3] = before[2, step].float(), before[6, step].float()                    # in-prompt rows keep the prompt
+    want = before.clone()
+    for r, d in enumerate(docs.tolist()):
+        want[d, step] = kept[r].to(dtype)
+    assert torch.equal(seqs, want)
+    prev = torch.stack([before[d, step - 1].float() for d in docs.tolist()])
+    c_eos = torch.nn.functional.cosine_similarity(eos, kept)
+    c_prev = torch.nn.functional.cosine_similarity(prev, kept)
+    assert (cos[:, 0] - c_eos).abs().max() <= 1e-5 and (cos[:, 1] - c_prev).abs().max() <= 1e-5
+    assert cos[0, 0] > 0.9999
+    # no row map, no prompt lengths, no EOS vector, first step: cosines are reported as 0
+    cos.fill_(-7.0)
+    hip.check(hip.lib.lcmhip_finalize_step(hip.ptr(new), hip.ptr(seqs), hip.dtype_code(dtype), None, None, 4, 0, total, dim,
+                                           None, hip.ptr(cos), _st(hip)))
+    torch.cuda.synchronize()
+    assert torch.equal(seqs[:4, 0], new.to(dtype)) and float(cos.abs().max()) == 0.0
+    assert hip.lib.lcmhip_finalize_step(hip.ptr(new), hip.ptr(seqs), hip.dtype_code(dtype), None, None, 4, total, total, dim,
+                                        None, hip.ptr(cos), _st(hip)) == -1
