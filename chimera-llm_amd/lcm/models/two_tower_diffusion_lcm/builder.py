@@ -167,16 +167,30 @@ def parameter_spec(config: TwoTowerDiffusionLCModelConfig,
 class DeviceSession:
     """Caches and scratch of one batch of documents inside a torch-owned workspace."""
 
-    def __init__(self, model: "TwoTowerDiffusionLCModel", max_batch: int, max_ctx: int, max_steps: int) -> None:
+    def __init__(self, model: "TwoTowerDiffusionLCModel", max_batch: int, max_ctx: int, max_steps: int,
+                 keep_context: bool = False) -> None:
         self.model = model
         self.dims = (max_batch, max_ctx, max_steps)
-        nbytes = C.c_size_t(0)
-        _hip.check(_hip.lib.lcmhip_session_workspace_bytes(model._handle, max_batch, max_ctx, max_steps, C.byref(nbytes)))
-        self.workspace = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=model.device)
-        base = (self.workspace.data_ptr() + 255) // 256 * 256
-        self._h = C.c_void_p()
-        _hip.check(_hip.lib.lcmhip_session_create(model._handle, max_batch, max_ctx, max_steps, C.c_void_p(base),
-                                                  nbytes.value, C.byref(self._h)))
+        # the library sizes and carves the fp32 copy of the contextualizer output only when LCMHIP_KEEP_CONTEXT is
+        # set while the session is created (tests set it globally; encode() without a state bag needs it per session)
+        import os
+        saved = os.environ.get("LCMHIP_KEEP_CONTEXT")
+        if keep_context:
+            os.environ["LCMHIP_KEEP_CONTEXT"] = "1"
+        try:
+            nbytes = C.c_size_t(0)
+            _hip.check(_hip.lib.lcmhip_session_workspace_bytes(model._handle, max_batch, max_ctx, max_steps, C.byref(nbytes)))
+            self.workspace = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=model.device)
+            base = (self.workspace.data_ptr() + 255) // 256 * 256
+            self._h = C.c_void_p()
+            _hip.check(_hip.lib.lcmhip_session_create(model._handle, max_batch, max_ctx, max_steps, C.c_void_p(base),
+                                                      nbytes.value, C.byref(self._h)))
+        finally:
+            if keep_context:
+                if saved is None:
+                    del os.environ["LCMHIP_KEEP_CONTEXT"]
+                else:
+                    os.environ["LCMHIP_KEEP_CONTEXT"] = saved
         self.schedule_key = None
 
     def __del__(self) -> None:
@@ -401,6 +415,22 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
                     t.copy_(torch.randn(shape, generator=g, device=t.device, dtype=torch.float32) * std)
         self._refresh_derived()
 
+    def _fold_versions(self) -> Tuple[int, ...]:
+        """In-place edit counters of the tensors the folded self-attention weights are computed from."""
+        out = []
+        for i in range(self.config.denoiser.num_layers):
+            p = f"denoiser.layers.{i}.self_attn"
+            for k in (f"{p}.output_proj.weight", f"{p}.output_proj.bias", f"{p}.v_proj.weight", f"{p}.v_proj.bias"):
+                t = self._params.get(k)
+                out.append(-1 if t is None else t._version)
+        return tuple(out)
+
+    def _ensure_folded(self) -> None:
+        """state_dict() hands out the live parameter tensors; if one that W_ov / b_ov derive from was edited in place
+        since the last fold (copy_, a perturbation in a test, ...), fold again before the weights are used."""
+        if getattr(self, "_folded_versions", None) != self._fold_versions():
+            self._refresh_derived()
+
     def _refresh_derived(self) -> None:
         if not getattr(self, "_handle", None):
             return
@@ -419,6 +449,7 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
                                             _hip.ptr(self._derived[f"{p}.ov_proj.bias"]), d, 1, d, d, _hip.EPI_STORE,
                                             code, None, 0, st))
         torch.cuda.current_stream(self.device).synchronize()   # wv_t temporaries may be freed after this
+        self._folded_versions = self._fold_versions()
 
     def state_dict(self) -> Dict[str, Tensor]:
         return self._params
@@ -494,6 +525,7 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
                 c.clip_sample, c.clip_sample_range, c.thresholding, c.dynamic_thresholding_ratio, c.sample_max_value)
 
     def acquire_session(self, max_batch: int, max_ctx: int, timesteps: Optional[List[int]] = None) -> DeviceSession:
+        self._ensure_folded()
         if timesteps is None:
             assert hasattr(self, "clip_noise"), (
                 "The model is not properly set for decoding, make sure to call `model.prep_for_denoising()`")
@@ -555,10 +587,16 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
     def encode(self, batch: EmbeddingsBatch, state_bag: Optional[LCMIncrementalStateBag] = None,
                *, normalized: bool = True, **kwargs) -> DeviceContext:
         """Contextualizes `batch.seqs` (normalized SONAR embeddings) after what the bag already holds."""
-        if state_bag is None:
-            raise NotImplementedError("encode() without a state bag (no KV cache) is not implemented on the HIP path")
         if batch.padding_mask is not None:
             raise ValueError("the contextualizer takes unpadded positions (the generator never pads them)")
+        if state_bag is None:
+            # reference builder.py:161-191 without a bag: a plain forward over the whole sequence.  A throw-away
+            # session that keeps the contextualizer output, so that `.seqs` of the result can be read back.
+            B, S = batch.seqs.shape[:2]
+            sess = DeviceSession(self, B, S, 1, keep_context=True)
+            sess.reset(B)
+            sess.append(batch.seqs, normalized=normalized)
+            return DeviceContext(sess, sess.context_len)
         sess = self._session_for(state_bag, batch.seqs.shape[0])
         sess.append(batch.seqs, normalized=normalized)
         return DeviceContext(sess, sess.context_len)

@@ -169,3 +169,40 @@ def test_rejected_schedule_leaves_no_stale_state():
     out = sess.denoise(torch.randn(2, 1024, device="cuda"))
     assert torch.isfinite(out).all()
     model.release_session(sess)
+
+
+def test_in_place_weight_edit_refolds_self_attention():
+    """The denoiser's self-attention runs on a folded W_o W_v; editing a v_proj through state_dict() in place must
+    reach the next generation (the fold is redone when a source tensor's in-place counter moved)."""
+    from lcm.models.two_tower_diffusion_lcm import create_two_tower_diffusion_lcm_model
+    cfg, sd, x, nz = make_problem(ARCH, 2, 3, 2)
+    opts = dict(DEFAULT_OPTS, inference_timesteps=5)
+    model = create_two_tower_diffusion_lcm_model(mini_config(), device="cuda:0", dtype=torch.float32)
+    model.load_state_dict(sd)
+    first = _hip_generate(model, x, nz, 2, opts)
+    sd2 = dict(sd)
+    key = "denoiser.layers.1.self_attn.v_proj.weight"
+    sd2[key] = sd[key] * 1.7 + 0.01
+    model.state_dict()[key].copy_(sd2[key])                       # in place, behind the model's back
+    out = _hip_generate(model, x, nz, 2, opts)
+    ref = run_oracle(cfg, sd2, x, nz, 2, opts)
+    worst, cos = compare(out.hypotheses, ref, sd2, start=3)
+    assert worst <= FP32_MAX_ABS and cos >= FP32_COS, (worst, cos)
+    w_old, _ = compare(first.hypotheses, ref, sd2, start=3)
+    assert w_old > 10 * FP32_MAX_ABS                                # the edit mattered
+
+
+def test_encode_without_a_state_bag():
+    """TwoTowerDiffusionLCModel.encode(batch) with no bag (reference builder.py:161-191): the contextualizer over the
+    whole sequence, readable through `.seqs`, equal to the oracle's encode."""
+    from lcm.datasets.batch import EmbeddingsBatch
+    from lcm.models.two_tower_diffusion_lcm import create_two_tower_diffusion_lcm_model
+    cfg, sd, x, _ = make_problem(ARCH, 3, 6, 1)
+    model = create_two_tower_diffusion_lcm_model(mini_config(), device="cuda:0", dtype=torch.float32)
+    model.load_state_dict(sd)
+    om = O.OracleTwoTower(cfg, sd)
+    xn = om.normalize(x)
+    want = om.encode(xn)
+    got = model.encode(EmbeddingsBatch(xn.cuda(), None)).seqs.float().cpu()
+    assert got.shape == want.shape
+    assert (got - want).abs().max() <= 1e-3 * max(1.0, float(want.abs().max()))
