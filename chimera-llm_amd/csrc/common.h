@@ -97,6 +97,42 @@ __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&v)[8]) {
     *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// Non-temporal forms for streams far larger than the caches (read once / written once): the lines do not displace
+// anything and stores go out without waiting in L2.  Measured on the copy calibration kernel at >= 256 MiB: +7 %.
+using nv_f4 = __attribute__((ext_vector_type(4))) float;
+using nv_u4 = __attribute__((ext_vector_type(4))) uint32_t;
+template <typename T, bool NT>
+__device__ __forceinline__ void load8x(const T* p, float (&v)[8]) {
+    if constexpr (!NT) {
+        load8<T>(p, v);
+    } else if constexpr (sizeof(T) == 4) {
+        const nv_f4 a = __builtin_nontemporal_load(reinterpret_cast<const nv_f4*>(p));
+        const nv_f4 b = __builtin_nontemporal_load(reinterpret_cast<const nv_f4*>(p) + 1);
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    } else {
+        const nv_u4 u = __builtin_nontemporal_load(reinterpret_cast<const nv_u4*>(p));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(u[i] << 16);
+            v[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u);
+        }
+    }
+}
+template <typename T, bool NT>
+__device__ __forceinline__ void store8x(T* p, const float (&v)[8]) {
+    if constexpr (!NT) {
+        store8<T>(p, v);
+    } else if constexpr (sizeof(T) == 4) {
+        __builtin_nontemporal_store(nv_f4{v[0], v[1], v[2], v[3]}, reinterpret_cast<nv_f4*>(p));
+        __builtin_nontemporal_store(nv_f4{v[4], v[5], v[6], v[7]}, reinterpret_cast<nv_f4*>(p) + 1);
+    } else {
+        nv_u4 w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
+        __builtin_nontemporal_store(w, reinterpret_cast<nv_u4*>(p));
+    }
+}
+
 // ---- wave / block reductions (wave = 64 lanes) --------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -267,6 +303,7 @@ __host__ __device__ inline size_t kv_cache_offset(int r, int n, int cap, int d) 
 }
 int launch_finalize_step(const float* new_emb, void* seqs, int dtype, const int32_t* doc_rows, const int32_t* prompt_lens,
                          int n_active, int step, int total_len, int dim, const float* eos, float* cos_out, hipStream_t st);
+int launch_stream_copy(const void* src, void* dst, int64_t bytes, int nontemporal, hipStream_t st);
 int launch_silu_cast(const float* x, void* y, int64_t n, int dtype, hipStream_t st);
 int launch_cast(const float* x, void* y, int64_t n, int dtype, hipStream_t st);
 int launch_broadcast_rows(const float* src, float* dst, int rows, int d, hipStream_t st);

@@ -1,63 +1,110 @@
 // Bandwidth-bound kernels of the generation path: SONAR normalizer, Layer/RMS norm fused with the
 // adaLN modulation, the fused DDIM + classifier-free-guidance update, RoPE + KV-cache scatter.
 // All of them read/write 16 bytes per lane, keep statistics in fp32 and reduce with wave shuffles.
+#include <algorithm>
+
 #include "common.h"
 
 namespace lcmhip {
 
+using vf4 = __attribute__((ext_vector_type(4))) float;   // native vector: what the non-temporal builtins take
+
+
 // ------------------------------------------------------------------------------------------------
 // SONAR normalizer: y = (x - center) / scale  [clamp]   |   y = [clamp](x) * scale + center
 // ------------------------------------------------------------------------------------------------
-// Lane i handles the 8-element vectors i, i + stride, ...; the launcher makes the stride a multiple of the row
-// length, so a lane stays on one column group: center / scale (and 1 / scale) are loaded once, and U vectors
-// are in flight per iteration.
-template <typename TI, typename TO, typename TP, bool INVERSE>
+// A workgroup walks whole tiles of 256 * U consecutive 8-element vectors (8 or 16 KB contiguous per tile: its requests
+// stay within a few DRAM pages -- a grid-wide stride between a lane's pieces costs a quarter of the rate).  When the
+// row length divides 256 vectors a lane stays on one column group for the whole launch: center / scale (and
+// 1 / scale) are loaded once.  NT: non-temporal loads and stores, for streams far larger than the caches.
+template <typename T, bool NT>
+__device__ __forceinline__ void load4x(const T* p, float (&v)[8]);
+template <>
+__device__ __forceinline__ void load4x<float, false>(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+}
+template <>
+__device__ __forceinline__ void load4x<float, true>(const float* p, float (&v)[8]) {
+    const nv_f4 a = __builtin_nontemporal_load(reinterpret_cast<const nv_f4*>(p));
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+}
+template <bool NT>
+__device__ __forceinline__ void store4x(float* p, const float (&v)[8]) {
+    if constexpr (NT) __builtin_nontemporal_store(nv_f4{v[0], v[1], v[2], v[3]}, reinterpret_cast<nv_f4*>(p));
+    else *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// VEC: elements per lane piece -- 8, or 4 when every operand is fp32 (a lane then moves 16 bytes per access: with 32
+// bytes per lane one wave instruction covers only half of every line it touches).
+template <typename TI, typename TO, typename TP, bool INVERSE, bool NT, int VEC = 8>
 __global__ __launch_bounds__(256) void k_normalizer(const TI* __restrict__ x, const TP* __restrict__ center,
                                                     const TP* __restrict__ scale, const TP* __restrict__ cmin,
                                                     const TP* __restrict__ cmax, TO* __restrict__ y, int64_t n_vec,
                                                     int vec_per_row) {
     constexpr int U = 4;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int col = (int)(i0 % vec_per_row) * 8;
-    float c[8], s[8], lo[8], hi[8];
-    load8<TP>(center + col, c);
-    load8<TP>(scale + col, s);
-    if (!INVERSE) {
-        // one exact division per column group, then a multiply per element (differs from a per-element division by
-        // at most one fp32 ulp; the division sequence would otherwise make the kernel VALU- rather than HBM-bound)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s[j] = 1.f / s[j];
-    }
+    const bool fixed_col = (256 % vec_per_row) == 0;
     const bool clip = cmin != nullptr;
-    if (clip) {
-        load8<TP>(cmin + col, lo);
-        load8<TP>(cmax + col, hi);
-    }
-    for (int64_t i = i0; i < n_vec; i += U * stride) {
+    float c[8], s[8], lo[8], hi[8];
+    auto params = [&](int col) {
+        if constexpr (VEC == 4) {
+            load4x<float, false>(reinterpret_cast<const float*>(center) + col, c);
+            load4x<float, false>(reinterpret_cast<const float*>(scale) + col, s);
+#pragma unroll
+            for (int j = 4; j < 8; ++j) { c[j] = 0.f; s[j] = 1.f; }
+        } else {
+            load8<TP>(center + col, c);
+            load8<TP>(scale + col, s);
+        }
+        if (!INVERSE) {
+            // one exact division per column group, then a multiply per element (differs from a per-element division by
+            // at most one fp32 ulp; the division sequence would otherwise make the kernel VALU- rather than HBM-bound)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] = 1.f / s[j];
+        }
+        if (clip) {
+            if constexpr (VEC == 4) {
+                load4x<float, false>(reinterpret_cast<const float*>(cmin) + col, lo);
+                load4x<float, false>(reinterpret_cast<const float*>(cmax) + col, hi);
+            } else {
+                load8<TP>(cmin + col, lo);
+                load8<TP>(cmax + col, hi);
+            }
+        }
+    };
+    if (fixed_col) params((int)(threadIdx.x % vec_per_row) * VEC);
+    const int64_t tiles = (n_vec + 256 * U - 1) / (256 * U);
+    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const int64_t i0 = t * 256 * U + threadIdx.x;
         float v[U][8];
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (i + u * stride < n_vec) load8<TI>(x + (i + u * stride) * 8, v[u]);
+            if (i0 + u * 256 < n_vec) {
+                if constexpr (VEC == 4) load4x<float, NT>(reinterpret_cast<const float*>(x) + (i0 + u * 256) * 4, v[u]);
+                else load8x<TI, NT>(x + (i0 + u * 256) * 8, v[u]);
+            }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (i + u * stride >= n_vec) break;
+            const int64_t i = i0 + u * 256;
+            if (i >= n_vec) break;
+            if (!fixed_col) params((int)(i % vec_per_row) * VEC);
             if (INVERSE) {
                 if (clip) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[u][j] = fminf(fmaxf(v[u][j], lo[j]), hi[j]);
+                    for (int j = 0; j < VEC; ++j) v[u][j] = fminf(fmaxf(v[u][j], lo[j]), hi[j]);
                 }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[u][j] = v[u][j] * s[j] + c[j];
+                for (int j = 0; j < VEC; ++j) v[u][j] = v[u][j] * s[j] + c[j];
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[u][j] = (v[u][j] - c[j]) * s[j];
+                for (int j = 0; j < VEC; ++j) v[u][j] = (v[u][j] - c[j]) * s[j];
                 if (clip) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[u][j] = fminf(fmaxf(v[u][j], lo[j]), hi[j]);
+                    for (int j = 0; j < VEC; ++j) v[u][j] = fminf(fmaxf(v[u][j], lo[j]), hi[j]);
                 }
             }
-            store8<TO>(y + (i + u * stride) * 8, v[u]);
+            if constexpr (VEC == 4) store4x<NT>(reinterpret_cast<float*>(y) + i * 4, v[u]);
+            else store8x<TO, NT>(y + i * 8, v[u]);
         }
     }
 }
@@ -69,30 +116,34 @@ static int grid_for(int64_t n_items, int block) {
     return (int)g;
 }
 
-// Grid of the normalizer: grid * 256 lanes must be a multiple of the vectors per row whenever a lane makes
-// more than one pass, so that it stays on its column group.
+// Grid of the normalizer: one workgroup per 1024-vector tile, at most 8 per CU.
 static int normalizer_grid(int64_t n_vec, int vec_per_row) {
-    int64_t g = (n_vec + 255) / 256;
-    if (g <= 2048) return (int)(g < 1 ? 1 : g);   // one pass
-    g = 2048;
-    while ((g * 256) % vec_per_row != 0) --g;     // vec_per_row <= 1024 here: terminates at a multiple
-    return (int)g;
+    (void)vec_per_row;
+    const int64_t tiles = (n_vec + 1023) / 1024;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(tiles, 4096));
 }
+
+// Streams this large gain from the non-temporal forms (they no longer fit the caches anyway).
+static bool use_nontemporal(int64_t bytes) { return bytes >= ((int64_t)128 << 20); }
 
 int launch_normalize(const void* x, const void* center, const void* scale, const void* cmin, const void* cmax,
                      void* y, int64_t rows, int dim, int dtype, bool inverse, hipStream_t st) {
     LCM_REQUIRE(dim % 8 == 0 && dim <= 8192 && rows >= 0, "normalizer: dim must be a multiple of 8, at most 8192");
     LCM_REQUIRE((cmin == nullptr) == (cmax == nullptr), "normalizer: clip_min and clip_max go together");
     if (rows == 0) return LCMHIP_OK;
-    const int64_t n_vec = rows * (dim / 8);
-    const int g = normalizer_grid(n_vec, dim / 8);
-#define LCM_NORMALIZER(T, INV)                                                                             \
-    hipLaunchKernelGGL((k_normalizer<T, T, T, INV>), dim3(g), dim3(256), 0, st, (const T*)x, (const T*)center, \
-                       (const T*)scale, (const T*)cmin, (const T*)cmax, (T*)y, n_vec, dim / 8)
+    const int vec = dtype == LCMHIP_F32 ? 4 : 8;          // 16 bytes per lane and access
+    const int64_t n_vec = rows * (dim / vec);
+    const int g = normalizer_grid(n_vec, dim / vec);
+    const bool nt = use_nontemporal(2 * rows * (int64_t)dim * (int64_t)dtype_size(dtype));
+#define LCM_NORMALIZER(T, INV, V)                                                                                   \
+    if (nt) hipLaunchKernelGGL((k_normalizer<T, T, T, INV, true, V>), dim3(g), dim3(256), 0, st, (const T*)x, (const T*)center, \
+                               (const T*)scale, (const T*)cmin, (const T*)cmax, (T*)y, n_vec, dim / V);             \
+    else hipLaunchKernelGGL((k_normalizer<T, T, T, INV, false, V>), dim3(g), dim3(256), 0, st, (const T*)x, (const T*)center,   \
+                            (const T*)scale, (const T*)cmin, (const T*)cmax, (T*)y, n_vec, dim / V)
     if (dtype == LCMHIP_BF16) {
-        if (inverse) LCM_NORMALIZER(bf16_t, true); else LCM_NORMALIZER(bf16_t, false);
+        if (inverse) { LCM_NORMALIZER(bf16_t, true, 8); } else { LCM_NORMALIZER(bf16_t, false, 8); }
     } else if (dtype == LCMHIP_F32) {
-        if (inverse) LCM_NORMALIZER(float, true); else LCM_NORMALIZER(float, false);
+        if (inverse) { LCM_NORMALIZER(float, true, 4); } else { LCM_NORMALIZER(float, false, 4); }
     } else {
         return fail(LCMHIP_ERR_INVALID, "normalizer: unknown dtype");
     }
@@ -108,11 +159,11 @@ int launch_normalize_f32_in(const float* x, const void* center, const void* scal
     const int64_t n_vec = rows * (dim / 8);
     const int g = normalizer_grid(n_vec, dim / 8);
     if (dtype == LCMHIP_BF16)
-        hipLaunchKernelGGL((k_normalizer<float, bf16_t, bf16_t, false>), dim3(g), dim3(256), 0, st, x,
+        hipLaunchKernelGGL((k_normalizer<float, bf16_t, bf16_t, false, false>), dim3(g), dim3(256), 0, st, x,
                            (const bf16_t*)center, (const bf16_t*)scale, (const bf16_t*)nullptr,
                            (const bf16_t*)nullptr, (bf16_t*)y, n_vec, dim / 8);
     else
-        hipLaunchKernelGGL((k_normalizer<float, float, float, false>), dim3(g), dim3(256), 0, st, x,
+        hipLaunchKernelGGL((k_normalizer<float, float, float, false, false>), dim3(g), dim3(256), 0, st, x,
                            (const float*)center, (const float*)scale, (const float*)nullptr, (const float*)nullptr,
                            (float*)y, n_vec, dim / 8);
     LCM_HIP_CHECK(hipGetLastError());
@@ -127,11 +178,11 @@ int launch_denormalize_f32_out(const float* x0, const void* center, const void* 
     const int64_t n_vec = rows * (dim / 8);
     const int g = normalizer_grid(n_vec, dim / 8);
     if (dtype == LCMHIP_BF16)
-        hipLaunchKernelGGL((k_normalizer<float, float, bf16_t, true>), dim3(g), dim3(256), 0, st, x0,
+        hipLaunchKernelGGL((k_normalizer<float, float, bf16_t, true, false>), dim3(g), dim3(256), 0, st, x0,
                            (const bf16_t*)center, (const bf16_t*)scale, (const bf16_t*)cmin,
                            (const bf16_t*)cmax, y, n_vec, dim / 8);
     else
-        hipLaunchKernelGGL((k_normalizer<float, float, float, true>), dim3(g), dim3(256), 0, st, x0,
+        hipLaunchKernelGGL((k_normalizer<float, float, float, true, false>), dim3(g), dim3(256), 0, st, x0,
                            (const float*)center, (const float*)scale, (const float*)cmin, (const float*)cmax,
                            y, n_vec, dim / 8);
     LCM_HIP_CHECK(hipGetLastError());
@@ -403,7 +454,7 @@ static bool try_norm_pending(float* x, const void* w, const void* b, const float
 
 // Many rows, nothing pending: one wave per row (4 rows per workgroup), the row in registers, statistics by wave
 // shuffles only -- no LDS, no barrier.  dim <= 4096, dim % 256 == 0.
-template <typename T, int KIND, int NV>
+template <typename T, int KIND, int NV, bool NT>
 __global__ __launch_bounds__(256) void k_norm_rows(const float* __restrict__ x, const T* __restrict__ w,
                                                    const T* __restrict__ b, const float* __restrict__ shift,
                                                    const float* __restrict__ scale, T* __restrict__ y, int rows, float eps,
@@ -420,7 +471,14 @@ __global__ __launch_bounds__(256) void k_norm_rows(const float* __restrict__ x, 
     const float* xr = x + (size_t)row * dim;
     float4 v[NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(xr + (lane + 64 * i) * 4);
+    for (int i = 0; i < NV; ++i) {
+        if constexpr (NT) {
+            const nv_f4 t = __builtin_nontemporal_load(reinterpret_cast<const nv_f4*>(xr + (lane + 64 * i) * 4));
+            v[i] = make_float4(t[0], t[1], t[2], t[3]);
+        } else {
+            v[i] = *reinterpret_cast<const float4*>(xr + (lane + 64 * i) * 4);
+        }
+    }
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i)
@@ -461,12 +519,14 @@ __global__ __launch_bounds__(256) void k_norm_rows(const float* __restrict__ x, 
             o[j] = t * (1.f + sc[j]) + sh[j];
         }
         if (sizeof(T) == 4) {
-            *reinterpret_cast<float4*>(reinterpret_cast<float*>(yr) + col) = make_float4(o[0], o[1], o[2], o[3]);
+            if constexpr (NT) __builtin_nontemporal_store(nv_f4{o[0], o[1], o[2], o[3]}, reinterpret_cast<nv_f4*>(reinterpret_cast<float*>(yr) + col));
+            else *reinterpret_cast<float4*>(reinterpret_cast<float*>(yr) + col) = make_float4(o[0], o[1], o[2], o[3]);
         } else {
             uint2 pk;
             pk.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
             pk.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
-            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(yr) + col) = pk;
+            if constexpr (NT) __builtin_nontemporal_store(((uint64_t)pk.y << 32) | pk.x, reinterpret_cast<uint64_t*>(reinterpret_cast<uint16_t*>(yr) + col));
+            else *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(yr) + col) = pk;
         }
     }
 }
@@ -475,14 +535,17 @@ template <typename T, int KIND>
 static bool launch_norm_rows(const float* x, const void* w, const void* b, const float* shift, const float* scale, void* y,
                              int rows, int dim, float eps, hipStream_t st, const RowSteps& rs) {
     const dim3 grid((rows + 3) / 4), block(256);
-#define LCM_ROWS(NV)                                                                                             \
-    hipLaunchKernelGGL((k_norm_rows<T, KIND, NV>), grid, block, 0, st, x, (const T*)w, (const T*)b, shift, scale, \
-                       (T*)y, rows, eps, rs)
+    const bool nt = use_nontemporal((int64_t)rows * dim * (4 + (int64_t)sizeof(T)));
+#define LCM_ROWS(NV)                                                                                                  \
+    if (nt) hipLaunchKernelGGL((k_norm_rows<T, KIND, NV, true>), grid, block, 0, st, x, (const T*)w, (const T*)b, shift, scale, \
+                               (T*)y, rows, eps, rs);                                                                  \
+    else hipLaunchKernelGGL((k_norm_rows<T, KIND, NV, false>), grid, block, 0, st, x, (const T*)w, (const T*)b, shift, scale,   \
+                            (T*)y, rows, eps, rs)
     switch (dim) {
-        case 256: LCM_ROWS(1); return true;
-        case 1024: LCM_ROWS(4); return true;
-        case 2048: LCM_ROWS(8); return true;
-        case 4096: LCM_ROWS(16); return true;
+        case 256: { LCM_ROWS(1); } return true;
+        case 1024: { LCM_ROWS(4); } return true;
+        case 2048: { LCM_ROWS(8); } return true;
+        case 4096: { LCM_ROWS(16); } return true;
         default: return false;
     }
 #undef LCM_ROWS
@@ -731,7 +794,7 @@ __global__ __launch_bounds__(256) void k_ddim_step(const float* __restrict__ sam
                 z[j] = z0;
             }
             *reinterpret_cast<float4*>(prev + base + ch * 4) = make_float4(p[0], p[1], p[2], p[3]);
-            *reinterpret_cast<float4*>(x0_out + base + ch * 4) = make_float4(z[0], z[1], z[2], z[3]);
+            if (x0_out != nullptr) *reinterpret_cast<float4*>(x0_out + base + ch * 4) = make_float4(z[0], z[1], z[2], z[3]);
             if (io.prev_cast != nullptr) {   // the next step's initial projection reads the latents in the operand dtype
                 if (io.bf16) {
                     uint2 pk;
@@ -743,6 +806,110 @@ __global__ __launch_bounds__(256) void k_ddim_step(const float* __restrict__ sam
                 }
             }
         }
+    }
+}
+
+
+// The same update for many rows of finished model outputs (no split-K slab, no thresholding): one wave per row,
+// 4 rows per workgroup, every operand of a row requested up front (3 * NV float4 per lane), statistics by wave
+// shuffles only -- no LDS, no barrier.  dim = 256 * NV.
+template <int NV>
+__global__ __launch_bounds__(256) void k_ddim_rows(const float* __restrict__ sample, const float* __restrict__ out_c,
+                                                   const float* __restrict__ out_u, float* __restrict__ prev,
+                                                   float* __restrict__ x0_out, int rows, DdimScalars sc,
+                                                   const float* __restrict__ variance_noise) {
+    constexpr int dim = 256 * NV;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;   // wave-uniform
+    const size_t base = (size_t)row * dim;
+    float4 xv[NV], cv[NV], uv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) xv[i] = *reinterpret_cast<const float4*>(sample + base + (lane + 64 * i) * 4);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) cv[i] = *reinterpret_cast<const float4*>(out_c + base + (lane + 64 * i) * 4);
+    if (sc.mode == 1) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) uv[i] = *reinterpret_cast<const float4*>(out_u + base + (lane + 64 * i) * 4);
+    }
+    float x[NV][4], e[NV][4], x0[NV][4];
+    if (sc.mode == 1) {
+        float c[NV][4];
+        float sum_c = 0.f, sum_g = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const float xs[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w}, cs[4] = {cv[i].x, cv[i].y, cv[i].z, cv[i].w},
+                        us[4] = {uv[i].x, uv[i].y, uv[i].z, uv[i].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                x[i][j] = xs[j];
+                const float ec = eps_from_output(cs[j], xs[j], sc);
+                const float eu = eps_from_output(us[j], xs[j], sc);
+                c[i][j] = ec;
+                e[i][j] = eu + sc.guidance_scale * (ec - eu);
+                sum_c += ec;
+                sum_g += e[i][j];
+            }
+        }
+        const float mean_c = wave_sum(sum_c) / dim, mean_g = wave_sum(sum_g) / dim;
+        float q_c = 0.f, q_g = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dc = c[i][j] - mean_c, dg = e[i][j] - mean_g;
+                q_c += dc * dc;
+                q_g += dg * dg;
+            }
+        const float std_pos = sqrtf(wave_sum(q_c) / (dim - 1));     // torch.std default: unbiased (n - 1)
+        const float std_cfg = sqrtf(wave_sum(q_g) / (dim - 1));
+        const float factor = sc.guidance_rescale * (std_pos / std_cfg) + (1.f - sc.guidance_rescale);
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                e[i][j] *= factor;
+                x0[i][j] = (x[i][j] - sc.sqrt_b_t * e[i][j]) / sc.sqrt_a_t;
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const float xs[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w}, cs[4] = {cv[i].x, cv[i].y, cv[i].z, cv[i].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                x[i][j] = xs[j];
+                if (sc.prediction_type == LCMHIP_PRED_EPSILON) {
+                    e[i][j] = cs[j];
+                    x0[i][j] = (xs[j] - sc.sqrt_b_t * cs[j]) / sc.sqrt_a_t;
+                } else if (sc.prediction_type == LCMHIP_PRED_SAMPLE) {
+                    x0[i][j] = cs[j];
+                    e[i][j] = (xs[j] - sc.sqrt_a_t * cs[j]) / sc.sqrt_b_t;
+                } else {
+                    x0[i][j] = sc.sqrt_a_t * xs[j] - sc.sqrt_b_t * cs[j];
+                    e[i][j] = sc.sqrt_a_t * cs[j] + sc.sqrt_b_t * xs[j];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const size_t off = base + (lane + 64 * i) * 4;
+        float4 vn = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (sc.sigma > 0.f) vn = *reinterpret_cast<const float4*>(variance_noise + off);
+        const float vns[4] = {vn.x, vn.y, vn.z, vn.w};
+        float p[4], z[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float ee = e[i][j] * sc.inv_eps_scaling;
+            float z0 = x0[i][j];
+            if (sc.clip_sample_range >= 0.f) z0 = fminf(fmaxf(z0, -sc.clip_sample_range), sc.clip_sample_range);
+            float pr = sc.sqrt_a_prev * z0 + sc.dir_coef * ee;
+            if (sc.sigma > 0.f) pr += sc.sigma * vns[j];
+            p[j] = fminf(fmaxf(pr, -sc.clip_noise), sc.clip_noise);
+            z[j] = z0;
+        }
+        __builtin_nontemporal_store(vf4{p[0], p[1], p[2], p[3]}, reinterpret_cast<vf4*>(prev + off));
+        if (x0_out != nullptr) __builtin_nontemporal_store(vf4{z[0], z[1], z[2], z[3]}, reinterpret_cast<vf4*>(x0_out + off));
     }
 }
 
@@ -759,6 +926,14 @@ int launch_ddim_step(const float* sample, const float* out_c, const float* out_u
     LCM_REQUIRE(sc.sigma <= 0.f || io.variance_noise != nullptr, "ddim: eta > 0 needs variance noise");
     LCM_REQUIRE(sc.thr_ratio < 0.f || (sc.thr_ratio <= 1.f && sc.thr_max >= 1.f), "ddim: bad thresholding parameters");
     if (rows <= 0) return LCMHIP_OK;
+    // many rows of finished outputs: the one-wave-per-row form (no LDS, no barriers, all loads up front)
+    if (rows >= 1024 && io.partial == nullptr && io.prev_cast == nullptr && sc.thr_ratio < 0.f && (dim == 1024 || dim == 2048)) {
+        const dim3 grid((rows + 3) / 4);
+        if (dim == 1024) hipLaunchKernelGGL((k_ddim_rows<4>), grid, dim3(256), 0, st, sample, out_c, out_u, prev, x0, rows, sc, io.variance_noise);
+        else hipLaunchKernelGGL((k_ddim_rows<8>), grid, dim3(256), 0, st, sample, out_c, out_u, prev, x0, rows, sc, io.variance_noise);
+        LCM_HIP_CHECK(hipGetLastError());
+        return LCMHIP_OK;
+    }
     hipLaunchKernelGGL(k_ddim_step, dim3(rows), dim3(256), 0, st, sample, out_c, out_u, prev, x0, dim, sc, io);
     LCM_HIP_CHECK(hipGetLastError());
     return LCMHIP_OK;
@@ -1025,6 +1200,66 @@ __global__ __launch_bounds__(256) void k_to_f32(const T* __restrict__ x, float* 
         load8<T>(x + i * 8, a);
         store8<float>(y + i * 8, a);
     }
+}
+
+// Stream-copy calibration: what the part delivers for a plain 16-byte-per-lane copy (the yardstick of the fused
+// elementwise kernels).  Grid sized to the CUs (8 workgroups per CU), four 16-byte pieces in flight per lane,
+// optionally non-temporal loads and stores.
+template <bool NT, bool TILED>
+__global__ __launch_bounds__(256) void k_stream_copy(const vf4* __restrict__ src, vf4* __restrict__ dst, int64_t n16) {
+    constexpr int U = 4;
+    if constexpr (TILED) {
+        // a workgroup walks whole 16-KB tiles (U contiguous 4-KB rows of pieces): its requests stay within few DRAM pages
+        const int64_t tiles = (n16 + 256 * U - 1) / (256 * U);
+        for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+            const int64_t i0 = t * 256 * U + threadIdx.x;
+            vf4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (i0 + u * 256 < n16) v[u] = NT ? __builtin_nontemporal_load(src + i0 + u * 256) : src[i0 + u * 256];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (i0 + u * 256 < n16) {
+                    if (NT) __builtin_nontemporal_store(v[u], dst + i0 + u * 256);
+                    else dst[i0 + u * 256] = v[u];
+                }
+        }
+    } else {
+        const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += U * stride) {
+            vf4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (i + u * stride < n16) v[u] = NT ? __builtin_nontemporal_load(src + i + u * stride) : src[i + u * stride];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (i + u * stride < n16) {
+                    if (NT) __builtin_nontemporal_store(v[u], dst + i + u * stride);
+                    else dst[i + u * stride] = v[u];
+                }
+        }
+    }
+}
+
+// mode bit 0: non-temporal loads / stores; bit 1: tile-contiguous walk instead of a grid-wide stride;
+// bits 8..: workgroups per CU (0 = 8)
+int launch_stream_copy(const void* src, void* dst, int64_t bytes, int mode, hipStream_t st) {
+    LCM_REQUIRE(bytes >= 0 && bytes % 16 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0,
+                "stream_copy: 16-byte aligned pointers and size");
+    if (bytes == 0) return LCMHIP_OK;
+    const int64_t n16 = bytes / 16;
+    const int per_cu = (mode >> 8) > 0 ? (mode >> 8) : 8;
+    const int g = (int)std::min<int64_t>(256 * per_cu, (n16 + 255) / 256);
+    const vf4* a = (const vf4*)src;
+    vf4* b = (vf4*)dst;
+    switch (mode & 3) {
+        case 0: hipLaunchKernelGGL((k_stream_copy<false, false>), dim3(g), dim3(256), 0, st, a, b, n16); break;
+        case 1: hipLaunchKernelGGL((k_stream_copy<true, false>), dim3(g), dim3(256), 0, st, a, b, n16); break;
+        case 2: hipLaunchKernelGGL((k_stream_copy<false, true>), dim3(g), dim3(256), 0, st, a, b, n16); break;
+        default: hipLaunchKernelGGL((k_stream_copy<true, true>), dim3(g), dim3(256), 0, st, a, b, n16); break;
+    }
+    LCM_HIP_CHECK(hipGetLastError());
+    return LCMHIP_OK;
 }
 
 int launch_copy_rows_to_f32(const void* src, float* dst, int64_t n, int dtype, hipStream_t st) {

@@ -1021,7 +1021,8 @@ static int denoise_body(lcmhip_session* s, const float* noise, float* out, float
             io.prev_cast = s->act_lat; io.bf16 = d.dtype == LCMHIP_BF16 ? 1 : 0;
             io.variance_noise = variance_noise ? variance_noise + (size_t)si * B * D : nullptr;
             ProfScope ps(&s->prof, "den.ddim_cfg_step", (double)B * D * 4.0 * (3.0 + fp.splits * (rows == 2 * B ? 2.0 : 1.0)), 0.0, st);
-            LCM_TRY(launch_ddim_step(lat, nullptr, nullptr, lat_next, s->x0, B, D, sc, st, &io));
+            // the predicted x0 is only read after the last step (denormalize)
+            LCM_TRY(launch_ddim_step(lat, nullptr, nullptr, lat_next, si + 1 == s->n_steps ? s->x0 : nullptr, B, D, sc, st, &io));
         }
         std::swap(lat, lat_next);
         if (latents_trace)
@@ -1298,7 +1299,7 @@ int lcmhip_residual_norm(float* x, const float* slab, int32_t splits, int32_t M,
 int lcmhip_ddim_cfg_step(const float* sample, const float* out_cond, const float* out_uncond, float* prev_sample,
                          float* pred_x0, int32_t rows, int32_t dim, float alpha_prod_t, float alpha_prod_t_prev,
                          const lcmhip_denoise_params* p, const float* variance_noise, void* stream) {
-    LCM_REQUIRE(sample && out_cond && prev_sample && pred_x0 && p, "ddim_cfg_step: null argument");
+    LCM_REQUIRE(sample && out_cond && prev_sample && p, "ddim_cfg_step: null argument");
     LCM_REQUIRE(p->ddim_eta >= 0.f, "ddim_cfg_step: ddim_eta must not be negative");
     LCM_REQUIRE(p->ddim_eta == 0.f || variance_noise != nullptr, "ddim_cfg_step: ddim_eta > 0 needs variance noise");
     DdimScalars sc{};
@@ -1321,6 +1322,11 @@ int lcmhip_ddim_cfg_step(const float* sample, const float* out_cond, const float
     DdimIO io;
     io.variance_noise = variance_noise;
     return launch_ddim_step(sample, out_cond, out_uncond, prev_sample, pred_x0, rows, dim, sc, static_cast<hipStream_t>(stream), &io);
+}
+
+int lcmhip_stream_copy(const void* src, void* dst, int64_t bytes, int32_t nontemporal, void* stream) {
+    LCM_REQUIRE(src && dst, "stream_copy: null argument");
+    return launch_stream_copy(src, dst, bytes, nontemporal, static_cast<hipStream_t>(stream));
 }
 
 int lcmhip_finalize_step(const float* new_emb, void* seqs, int32_t seqs_dtype, const int32_t* doc_rows,

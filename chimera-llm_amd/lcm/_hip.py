@@ -32,7 +32,7 @@ EXPORTS = [
     "lcmhip_session_read_context", "lcmhip_session_profile_enable", "lcmhip_session_profile",
     "lcmhip_normalize", "lcmhip_denormalize", "lcmhip_norm_modulate", "lcmhip_gemm", "lcmhip_gemm_static", "lcmhip_gemm_partial",
     "lcmhip_residual_norm",
-    "lcmhip_ddim_cfg_step", "lcmhip_attention", "lcmhip_finalize_step",
+    "lcmhip_ddim_cfg_step", "lcmhip_attention", "lcmhip_finalize_step", "lcmhip_stream_copy",
 ]
 
 
@@ -101,6 +101,7 @@ def _load() -> C.CDLL:
         "lcmhip_residual_norm": [vp, vp, i32, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
         "lcmhip_ddim_cfg_step": [vp, vp, vp, vp, vp, i32, i32, f32, f32, C.POINTER(DenoiseParams), vp, vp],
         "lcmhip_attention": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+        "lcmhip_stream_copy": [vp, vp, i64, i32, vp],
         "lcmhip_finalize_step": [vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp],
     }
     for name, argtypes in sig.items():

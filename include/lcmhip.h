@@ -300,7 +300,7 @@ int lcmhip_gemm_partial(const void* A, int32_t lda, const void* W, float* slab, 
  * (builder.py:463-488), DDIMScheduler.step (ddim.py:358-510, eta = 0) and the latent clip of
  * builder.py:452-454.  sample: (rows, dim) fp32 x_t; out_cond / out_uncond: (rows, dim) fp32
  * model outputs (out_uncond NULL: no guidance, `step` is applied to out_cond with the model's
- * prediction type); prev_sample, pred_x0: (rows, dim) fp32.  `variance_noise` (rows, dim) fp32 is required when
+ * prediction type); prev_sample, pred_x0: (rows, dim) fp32; pred_x0 may be NULL when only prev_sample is wanted.  `variance_noise` (rows, dim) fp32 is required when
  * params->ddim_eta > 0 and ignored otherwise.  With params->thresholding the predicted x0 of every row is divided
  * by s = clamp(quantile(|x0|, ratio), 1, sample_max_value) after clamping to [-s, s] (torch.quantile's linear
  * interpolation). */
@@ -308,6 +308,11 @@ int lcmhip_ddim_cfg_step(const float* sample, const float* out_cond, const float
                          float* prev_sample, float* pred_x0, int32_t rows, int32_t dim,
                          float alpha_prod_t, float alpha_prod_t_prev,
                          const lcmhip_denoise_params* params, const float* variance_noise, void* stream);
+
+/* Roofline calibration, no counterpart in the reference: copies `bytes` (a multiple of 16) from src to dst with 16
+ * bytes per lane, four pieces in flight per lane and a grid sized to the compute units; nontemporal != 0 uses
+ * non-temporal loads and stores.  The rate it reaches is the yardstick the fused elementwise kernels are held to. */
+int lcmhip_stream_copy(const void* src, void* dst, int64_t bytes, int32_t nontemporal, void* stream);
 
 /* The tensor work of finalize_step (lcm/inference/two_tower_diffusion_lcm/generator.py:305-351, 403; the base
  * generator's lcm/inference/lcm/generator.py:288-330 is the same): for active row r of document doc_rows[r] (NULL:

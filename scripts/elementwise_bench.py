@@ -27,6 +27,9 @@ D = 1024
 for dt, es in ((torch.bfloat16, 2), (torch.float32, 4)):
     a = torch.randn(ROWS, D, device=dev).to(dt); b = torch.empty_like(a)
     timeit(lambda: b.copy_(a), 2 * ROWS * D * es, f"torch copy_ {dt}".replace("torch.", "", 1))
+    for nt in (0, 1):       # the library's own calibration copy: 16 B per lane, 16-KB tiles per workgroup, 16 workgroups per CU
+        timeit(lambda: _hip.check(_hip.lib.lcmhip_stream_copy(_hip.ptr(a), _hip.ptr(b), a.numel() * es, 2 | nt | (16 << 8), st)),
+               2 * ROWS * D * es, f"stream_copy {'nt ' if nt else ''}{dt}".replace("torch.", ""))
 for dt, code, es in ((torch.bfloat16, _hip.BF16, 2), (torch.float32, _hip.F32, 4)):
     x = torch.randn(ROWS, D, device=dev).to(dt); y = torch.empty_like(x)
     c = torch.randn(D, device=dev).to(dt); s = (torch.rand(D, device=dev) + 0.5).to(dt)
@@ -47,4 +50,7 @@ par = _hip.DenoiseParams(3.0, 0.7, 0.0, 0.0, 100.0, 0.6, 0, 0, 1.0, 0, 0.995, 1.
 timeit(lambda: _hip.check(_hip.lib.lcmhip_ddim_cfg_step(_hip.ptr(x), _hip.ptr(oc), _hip.ptr(ou), _hip.ptr(prev), _hip.ptr(x0), ROWS, D,
                                                          0.5, 0.6, C.byref(par), None, st)),
        5 * ROWS * D * 4, "ddim+cfg step f32 (3 in, 2 out)")
+timeit(lambda: _hip.check(_hip.lib.lcmhip_ddim_cfg_step(_hip.ptr(x), _hip.ptr(oc), _hip.ptr(ou), _hip.ptr(prev), None, ROWS, D,
+                                                         0.5, 0.6, C.byref(par), None, st)),
+       4 * ROWS * D * 4, "ddim+cfg step f32 (3 in, 1 out)")
 print(json.dumps({"rows": ROWS, "peak_GBps": PEAK, "kernels": res}))

@@ -391,3 +391,47 @@ def test_finalize_step(hip, dtype):
     assert torch.equal(seqs[:4, 0], new.to(dtype)) and float(cos.abs().max()) == 0.0
     assert hip.lib.lcmhip_finalize_step(hip.ptr(new), hip.ptr(seqs), hip.dtype_code(dtype), None, None, 4, total, total, dim,
                                         None, hip.ptr(cos), _st(hip)) == -1
+
+
+@pytest.mark.parametrize("dim", [1024, 2048])
+@pytest.mark.parametrize("mode", ["plain_sample", "cfg"])
+def test_ddim_cfg_step_many_rows(hip, mode, dim):
+    """From 1024 rows of finished outputs the update runs one wave per row; same arithmetic as the one-workgroup-per-row
+    kernel (checked against it and against the oracle's scheduler), with and without the predicted-x0 output."""
+    import oracle
+    from oracle.archs import SchedulerConfig
+    torch.manual_seed(5)
+    rows = 1027
+    sch = oracle.DDIMSchedule(SchedulerConfig(num_train_steps=100))
+    sch.set_timesteps(40)
+    t = 31
+    x = torch.randn(rows, 1, dim) * 0.8
+    oc, ou, vn = torch.randn(rows, 1, dim), torch.randn(rows, 1, dim), torch.randn(rows, 1, dim)
+    a_t, a_prev = sch._alphas(t)
+    p = hip.DenoiseParams(guidance_scale=3.0, guidance_rescale=0.7, ddim_eta=0.3, epsilon_scaling=0.0, clip_noise=2.5,
+                          init_noise_sigma=1.0, prediction_type=hip.PRED["sample"], clip_sample=0, clip_sample_range=1.0,
+                          thresholding=0, dynamic_thresholding_ratio=0.995, sample_max_value=1.0)
+    if mode == "cfg":
+        class M:
+            guidance_scale, guidance_rescale = 3.0, 0.7
+        eps = oracle.OracleTwoTower.apply_cfg(M, sch.get_epsilon(torch.cat([oc, ou]), torch.cat([x, x]), t))
+        prev, x0 = sch.step(eps, t, x, prediction_type="epsilon", eta=0.3, variance_noise=vn)
+    else:
+        prev, x0 = sch.step(oc, t, x, eta=0.3, variance_noise=vn)
+    prev = prev.clip(-2.5, 2.5)
+    g = lambda a: a.reshape(rows, dim).cuda()        # noqa: E731
+    xg, ocg, oug, vng = g(x), g(oc), g(ou), g(vn)
+    pg, zg = torch.empty_like(xg), torch.empty_like(xg)
+    hip.check(hip.lib.lcmhip_ddim_cfg_step(hip.ptr(xg), hip.ptr(ocg), hip.ptr(oug) if mode == "cfg" else None, hip.ptr(pg),
+                                           hip.ptr(zg), rows, dim, float(a_t), float(a_prev), C.byref(p), hip.ptr(vng), _st(hip)))
+    assert (pg.cpu() - prev.reshape(rows, dim)).abs().max() <= 2e-5
+    assert (zg.cpu() - x0.reshape(rows, dim)).abs().max() <= 2e-5 * max(1.0, float(x0.abs().max()))
+    p2 = torch.empty_like(xg)
+    hip.check(hip.lib.lcmhip_ddim_cfg_step(hip.ptr(xg), hip.ptr(ocg), hip.ptr(oug) if mode == "cfg" else None, hip.ptr(p2),
+                                           None, rows, dim, float(a_t), float(a_prev), C.byref(p), hip.ptr(vng), _st(hip)))
+    assert torch.equal(p2, pg)
+    # the first 5 rows through the small-batch kernel
+    p3, z3 = torch.empty(5, dim, device="cuda"), torch.empty(5, dim, device="cuda")
+    hip.check(hip.lib.lcmhip_ddim_cfg_step(hip.ptr(xg), hip.ptr(ocg), hip.ptr(oug) if mode == "cfg" else None, hip.ptr(p3),
+                                           hip.ptr(z3), 5, dim, float(a_t), float(a_prev), C.byref(p), hip.ptr(vng), _st(hip)))
+    assert (p3 - pg[:5]).abs().max() <= 1e-5
