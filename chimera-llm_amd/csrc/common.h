@@ -194,6 +194,11 @@ struct GemmArgs {
     // split-K: fp32 slab [splits][M][N] (optional; without it the K range is never split)
     float* partial; size_t partial_bytes; int max_splits;
     int tiles_x, tiles_y;       // filled by the launcher of the 256 x 256 kernel (tile grid behind its 1-D launch)
+    // Stacked products (stack = 2 or 3; 0 / 1 = off): `stack` weight matrices of N rows each are multiplied by the same
+    // A in one launch, matrix g >= 1 with its own weight, bias and output (matrix 0 uses W / bias / out).  Linear
+    // epilogues without a K split only; every output shares ldo, out_rows and out_head_cap.
+    int stack;
+    const void* stack_W[2]; const void* stack_bias[2]; void* stack_out[2];
 };
 // C = A W^T with the epilogue applied (split-K + finishing pass when a.partial is given and it pays).
 int launch_gemm(const GemmArgs& a, hipStream_t st);

@@ -522,6 +522,20 @@ int launch_gemm_partial(const GemmArgs& a, int* splits, hipStream_t st) {
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
     LCM_TRY(check_args(a));
     LCM_REQUIRE(a.out != nullptr && a.ldo % 4 == 0 && ((uintptr_t)a.out % 16) == 0, "gemm: output must be 16-byte aligned");
+    if (a.stack > 1) {
+        // stacked matrices over one A: a single launch of a many-row kernel when the stack as a whole fills the chip
+        // without a K split, otherwise one product per matrix
+        LCM_REQUIRE(a.stack <= 3 && (a.epilogue == LCMHIP_EPI_STORE || a.epilogue == LCMHIP_EPI_STORE_F32 || a.epilogue == LCMHIP_EPI_RELU),
+                    "gemm: stacked products take up to 3 matrices and a linear epilogue");
+        if (gemm_big_applicable(a, false)) return launch_gemm_big(a, a.epilogue, 1, a.M, st);
+        for (int g = 0; g < a.stack; ++g) {
+            GemmArgs one = a;
+            one.stack = 0;
+            if (g > 0) { one.W = a.stack_W[g - 1]; one.bias = a.stack_bias[g - 1]; one.out = a.stack_out[g - 1]; }
+            LCM_TRY(launch_gemm(one, st));
+        }
+        return LCMHIP_OK;
+    }
     const bool can_split = a.partial != nullptr && a.epilogue != LCMHIP_EPI_SWIGLU;
     if (gemm_big_applicable(a, can_split)) {
         int s = can_split ? gemm_big_splits(a, a.max_splits) : 1;

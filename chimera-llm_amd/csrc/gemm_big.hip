@@ -11,6 +11,7 @@
 // t + 1 runs while the matrix cores consume tile t; one barrier per K tile.  (A three-stage variant with one
 // workgroup per CU and a counted vmcnt across a bare s_barrier measured 20-25 % slower than two stages with two
 // workgroups per CU.)
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -25,6 +26,21 @@ constexpr int kRowB = 128;                      // bytes of K per tile row and s
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 }  // namespace
+
+// Stacked products: the weight-row tile index counts through all matrices.  Selects the tile's matrix (weight, bias,
+// output) in the workgroup's copy of the arguments and returns the tile index inside that matrix.
+__device__ __forceinline__ int big_select_matrix(GemmArgs& p, int bx, int tiles_per_matrix) {
+    if (p.stack > 1) {
+        const int g = bx / tiles_per_matrix;
+        bx -= g * tiles_per_matrix;
+        if (g > 0) {
+            p.W = p.stack_W[g - 1];
+            p.bias = p.stack_bias[g - 1];
+            p.out = p.stack_out[g - 1];
+        }
+    }
+    return bx;
+}
 
 // Residual values of one 32-row round of a wave's output tile, in the lane order in which big_epilogue stores it
 // (RESID only): requested ahead of the round -- round 0 by the kernel itself before the tile is staged (requesting
@@ -178,7 +194,7 @@ __global__ __launch_bounds__(128 * WMV) void k_gemm_big(GemmArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
-    const int bx = blockIdx.x, bz = blockIdx.z;
+    const int bx = big_select_matrix(p, blockIdx.x, p.N / kBN), bz = blockIdx.z;
     const int m0 = bz * BM;
     const size_t kbytes = (size_t)p.K * 2;
     const int nk = (int)(kbytes / kRowB);
@@ -314,7 +330,7 @@ __global__ __launch_bounds__(512) void k_gemm_big256(GemmArgs p) {
         const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
         const int band = L / (2 * nx), rem = L - band * 2 * nx;
         const int rows = min(2, ny - 2 * band);
-        bx = rem / rows;
+        bx = big_select_matrix(p, rem / rows, p.N / 256);
         by = 2 * band + rem % rows;
     }
     const int m0 = by * 256;
@@ -517,7 +533,8 @@ int gemm_big_splits(const GemmArgs& a, int max_splits) {
 // 384 rows the 128 x 128 kernel wins by 7 %).
 bool gemm_big_applicable(const GemmArgs& a, bool may_split) {
     static const int min_rows = [] { const char* e = getenv("LCMHIP_BIG_MIN_ROWS"); return e ? atoi(e) : 384; }();
-    const int wrows = a.epilogue == LCMHIP_EPI_SWIGLU ? 2 * a.N : a.N;
+    const int wrows = (a.epilogue == LCMHIP_EPI_SWIGLU ? 2 * a.N : a.N) * std::max(1, a.stack);
+    if (a.stack > 1 && a.N % kBN != 0) return false;
     if (!(a.dtype == LCMHIP_BF16 && a.M >= min_rows && a.K % 64 == 0 && wrows % kBN == 0 && a.lda % 8 == 0)) return false;
     const int tiles = (wrows / kBN) * ((a.M + kBM - 1) / kBM);
     const int s = may_split ? gemm_big_splits(a, a.max_splits) : 1;
@@ -538,7 +555,8 @@ static bool big256_applicable(const GemmArgs& a, int epi, int splits, int m_rows
     static const int mode = [] { const char* e = getenv("LCMHIP_BIG256"); return e ? atoi(e) : 1; }();
     static const int min_tiles = [] { const char* e = getenv("LCMHIP_BIG256_MIN_TILES"); return e ? atoi(e) : 0; }();
     if (mode == 0 || splits != 1 || epi == EPI_PARTIAL) return false;
-    const int wrows = epi == LCMHIP_EPI_SWIGLU ? 2 * a.N : a.N;
+    if (a.N % 256 != 0 && a.stack > 1) return false;
+    const int wrows = (epi == LCMHIP_EPI_SWIGLU ? 2 * a.N : a.N) * std::max(1, a.stack);
     if (wrows % 256 != 0 || a.K % 64 != 0 || a.K < 128) return false;
     if ((size_t)a.M * a.lda * 2 >= (1ull << 31) || (size_t)wrows * a.K * 2 >= (1ull << 31)) return false;
     const int tiles = (wrows / 256) * ((m_rows + 255) / 256);
@@ -549,7 +567,7 @@ static bool big256_applicable(const GemmArgs& a, int epi, int splits, int m_rows
 }
 
 static int launch_gemm_big256(const GemmArgs& a_in, int epi, int m_rows, hipStream_t st) {
-    const int wrows = epi == LCMHIP_EPI_SWIGLU ? 2 * a_in.N : a_in.N;
+    const int wrows = (epi == LCMHIP_EPI_SWIGLU ? 2 * a_in.N : a_in.N) * std::max(1, a_in.stack);
     GemmArgs a = a_in;
     a.tiles_x = wrows / 256;
     a.tiles_y = (m_rows + 255) / 256;
@@ -575,8 +593,11 @@ static int launch_gemm_big256(const GemmArgs& a_in, int epi, int m_rows, hipStre
 }
 
 int launch_gemm_big(const GemmArgs& a, int epi, int splits, int m_rows, hipStream_t st) {
+    if (a.stack > 1)
+        LCM_REQUIRE(a.stack <= 3 && splits == 1 && a.N % kBN == 0 && (epi == LCMHIP_EPI_STORE || epi == LCMHIP_EPI_STORE_F32 || epi == LCMHIP_EPI_RELU),
+                    "gemm: stacked products take up to 3 matrices, a linear epilogue and no K split");
     if (big256_applicable(a, epi, splits, m_rows)) return launch_gemm_big256(a, epi, m_rows, st);
-    const int wrows = epi == LCMHIP_EPI_SWIGLU ? 2 * a.N : a.N;
+    const int wrows = (epi == LCMHIP_EPI_SWIGLU ? 2 * a.N : a.N) * std::max(1, a.stack);
     // (256 x 128 tiles with 8 waves and one workgroup per CU measured 10-20 % slower than two 128 x 128 workgroups.)
     dim3 grid(wrows / kBN, splits, (m_rows + kBM - 1) / kBM), block(256);
 #define LCM_BIG(E) hipLaunchKernelGGL((k_gemm_big<E, 2>), grid, block, 0, st, a)

@@ -193,6 +193,7 @@ struct lcmhip_session {
     lcmhip_model* model = nullptr;
     int max_batch = 0, cap = 0, max_steps = 0, rows_cap = 0, chunk_rows = 0;
     bool keep_context = false;
+    bool stack_products = true;     // q / k / v (and cross k / v) of many rows in one launch; LCMHIP_STACK=0 turns it off
     // carved device buffers
     int32_t *slot_map = nullptr, *pos_rows = nullptr, *self_rows = nullptr, *cross_rows = nullptr, *slot0_rows = nullptr;
     char *self_k = nullptr, *self_v = nullptr, *cross_k = nullptr, *cross_v = nullptr;
@@ -453,6 +454,36 @@ static int gemm(lcmhip_session* s, const char* tag, const void* A, int lda, cons
     return launch_gemm(a, st);
 }
 
+// Two or three Linears over the same rows (q / k / v, or a layer's cross-attention k / v): one launch of a many-row
+// kernel when the stacked weight rows fill the chip, otherwise one product each (see launch_gemm).
+static int gemm_stack(lcmhip_session* s, const char* tag, const void* A, int lda, int n, const Lin* const* W,
+                      void* const* outs, int ldo, int M, hipStream_t st, const int32_t* out_rows = nullptr,
+                      int out_head_cap = 0) {
+    GemmArgs a = gemm_args(s, A, lda, *W[0], nullptr, M, LCMHIP_EPI_STORE);
+    a.out = outs[0]; a.ldo = ldo; a.out_rows = out_rows; a.out_head_cap = out_head_cap;
+    a.partial = s->slab_q; a.partial_bytes = s->slab_bytes;
+    bool same = s->stack_products;
+    for (int g = 1; g < n; ++g) {
+        same = same && W[g]->out == W[0]->out && W[g]->in == W[0]->in && (W[g]->b != nullptr) == (W[0]->b != nullptr);
+        a.stack_W[g - 1] = W[g]->w; a.stack_bias[g - 1] = W[g]->b; a.stack_out[g - 1] = outs[g];
+    }
+    double bytes, flops;
+    gemm_cost(a, (double)dtype_size(a.dtype), &bytes, &flops);
+    if (same) {
+        a.stack = n;
+        ProfScope ps(&s->prof, tag, bytes * n, flops * n, st);
+        return launch_gemm(a, st);
+    }
+    for (int g = 0; g < n; ++g) {
+        GemmArgs one = gemm_args(s, A, lda, *W[g], nullptr, M, LCMHIP_EPI_STORE);
+        one.out = outs[g]; one.ldo = ldo; one.out_rows = out_rows; one.out_head_cap = out_head_cap;
+        one.partial = s->slab_q; one.partial_bytes = s->slab_bytes;
+        ProfScope ps(&s->prof, tag, bytes, flops, st);
+        LCM_TRY(launch_gemm(one, st));
+    }
+    return LCMHIP_OK;
+}
+
 // Product left in slab_p for the next norm kernel to fold into the residual stream.
 static int gemm_pending(lcmhip_session* s, const char* tag, const void* A, int lda, const Lin& W, const float* gate,
                         int M, Pending* pend, hipStream_t st, float* slab = nullptr) {
@@ -628,6 +659,10 @@ static int session_dims(lcmhip_session* s, const lcmhip_model* m, int max_batch,
     s->chunk_rows = std::max(2 * max_batch, (int)std::min<int64_t>(4096, std::max<int64_t>(512, (int64_t)max_batch * max_ctx)));
     s->rows_cap = std::max(s->chunk_rows, max_steps);
     s->keep_context = env_flag("LCMHIP_KEEP_CONTEXT");
+    {
+        const char* e = getenv("LCMHIP_STACK");
+        s->stack_products = !(e && e[0] == '0');
+    }
     return LCMHIP_OK;
 }
 
@@ -871,9 +906,11 @@ static int append_impl(lcmhip_session* s, const float* x, int32_t n_tokens, int3
             for (int l = 0; l < tc.num_layers; ++l) {
                 const CtxLayer& L = m->ctx[l];
                 LCM_TRY(norm(s, "ctx.norm", s->xres, L.sa_norm, nullptr, nullptr, s->act_a, R, R, tc.norm_kind, nullptr, st));
-                LCM_TRY(gemm(s, "ctx.qkv", s->act_a, dm, L.sa.q, nullptr, nullptr, s->act_q, dm, R, LCMHIP_EPI_STORE, st));
-                LCM_TRY(gemm(s, "ctx.qkv", s->act_a, dm, L.sa.k, nullptr, nullptr, s->act_k, dm, R, LCMHIP_EPI_STORE, st));
-                LCM_TRY(gemm(s, "ctx.qkv", s->act_a, dm, L.sa.v, nullptr, nullptr, s->act_v, dm, R, LCMHIP_EPI_STORE, st));
+                {
+                    const Lin* const w3[3] = {&L.sa.q, &L.sa.k, &L.sa.v};
+                    void* const o3[3] = {s->act_q, s->act_k, s->act_v};
+                    LCM_TRY(gemm_stack(s, "ctx.qkv", s->act_a, dm, 3, w3, o3, dm, R, st));
+                }
                 {
                     ProfScope ps(&s->prof, "ctx.rope_store", 5.0 * R * dm * es, 0.0, st);
                     LCM_TRY(launch_rope_store(s->act_q, s->act_k, s->act_v, s->self_k + l * self_layer, s->self_v + l * self_layer,
@@ -893,10 +930,9 @@ static int append_impl(lcmhip_session* s, const float* x, int32_t n_tokens, int3
             LCM_TRY(norm(s, "ctx.norm", s->xres, m->ctx_final, nullptr, nullptr, s->act_a, R, R, tc.norm_kind, nullptr, st));
             // cross-attention keys / values of the new context positions, every denoiser layer
             for (int l = 0; l < d.denoiser.num_layers; ++l) {
-                LCM_TRY(gemm(s, "ctx.cross_kv", s->act_a, dm, m->den[l].ca.k, nullptr, nullptr, s->cross_k + l * cross_layer, dm, R,
-                             LCMHIP_EPI_STORE, st, s->cross_rows, 0, nullptr, s->cap + 1));
-                LCM_TRY(gemm(s, "ctx.cross_kv", s->act_a, dm, m->den[l].ca.v, nullptr, nullptr, s->cross_v + l * cross_layer, dm, R,
-                             LCMHIP_EPI_STORE, st, s->cross_rows, 0, nullptr, s->cap + 1));
+                const Lin* const w2[2] = {&m->den[l].ca.k, &m->den[l].ca.v};
+                void* const o2[2] = {s->cross_k + l * cross_layer, s->cross_v + l * cross_layer};
+                LCM_TRY(gemm_stack(s, "ctx.cross_kv", s->act_a, dm, 2, w2, o2, dm, R, st, s->cross_rows, s->cap + 1));
             }
             if (s->keep_context) {
                 if (d.dtype == LCMHIP_BF16)

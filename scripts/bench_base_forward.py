@@ -20,15 +20,28 @@ x = (c + s * torch.randn(B, S, 1024, generator=g, device=dev)).to(torch.bfloat16
 def step():
     return model.predict_next_sentence(EmbeddingsBatch(x, None)).seqs
 
-for _ in range(2):
-    out = step()
-torch.cuda.synchronize()
-K = 5
-t0 = time.perf_counter()
-for _ in range(K):
-    out = step()
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / K
+def measure(K):
+    for _ in range(2):
+        out = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        out = step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / K, out
+
+# BF_AB=1: the stacked q / k / v product against three separate ones, alternating in one process (a session reads
+# LCMHIP_STACK when it is created)
+if os.environ.get("BF_AB"):
+    for rnd in range(3):
+        for mode in ("1", "0"):
+            os.environ["LCMHIP_STACK"] = mode
+            model._session_pool.clear()
+            dt, _ = measure(10)
+            print(f"round {rnd} LCMHIP_STACK={mode}: {dt * 1e3:.2f} ms per forward", flush=True)
+    os.environ["LCMHIP_STACK"] = "1"
+    model._session_pool.clear()
+dt, out = measure(int(os.environ.get("BF_STEPS", "10")))
 assert torch.isfinite(out).all()
 d, F, L, H = cfg.model_dim, cfg.lcm.allocated_ffn_dim(), cfg.lcm.num_layers, cfg.lcm.num_attn_heads
 rows = B * S

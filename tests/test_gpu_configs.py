@@ -158,6 +158,23 @@ def test_config2_base_lcm_1_6b_forward():
         d_sub = rms(sub[i], full[i].cpu())
         print(f"  row {i}: rms alone-vs-batch {d_alone:.4f}, pair-vs-batch {d_sub:.4f} (floor {d_ee:.4f})")
         assert d_alone <= NOISE_RATIO * d_ee and d_sub <= NOISE_RATIO * d_ee, (i, d_alone, d_sub, d_ee)
+    # q / k / v of 4096 rows run as ONE launch over the three stacked weight matrices; the same tiles in three launches
+    # (a session created with LCMHIP_STACK=0) give the same bits.  At 256 rows the three separate products split K
+    # (another summation order): bounded by the floor.
+    import os
+    model._session_pool.clear()
+    os.environ["LCMHIP_STACK"] = "0"
+    try:
+        full_unstacked = fwd(slice(0, 32))
+        model._session_pool.clear()
+        sub_unstacked = fwd(slice(0, 2)).cpu()
+    finally:
+        del os.environ["LCMHIP_STACK"]
+        model._session_pool.clear()
+    assert torch.equal(full_unstacked, full)
+    d_stack = rms(sub_unstacked, sub)
+    print(f"  2 x 128: rms stacked-vs-separate q/k/v products {d_stack:.4f} (floor {d_ee:.4f})")
+    assert d_stack <= NOISE_RATIO * d_ee, (d_stack, d_ee)
     del model
 
 
