@@ -13,7 +13,7 @@ B = int(os.environ.get("LC_BATCH", "512")); P = int(os.environ.get("LC_PROMPT", 
 dev = torch.device("cuda:0")
 model = create_two_tower_diffusion_lcm_model(lcm_archs.get_config(bench.ARCH), device=dev, dtype=torch.bfloat16, seed=0)
 model.init_parameters(seed=0, modulator_std=0.2)
-opts = dict(bench.OPTS, inference_timesteps=100, max_seq_len=max(G, 128))
+opts = dict(bench.OPTS, inference_timesteps=int(os.environ.get("LC_STEPS", "100")), max_seq_len=max(G, 128))
 gen = TwoTowerDiffusionLCMGenerator(model, DiffusionLCMGeneratorOptions(**opts))
 c, s = model.sonar_normalizer.center.float(), model.sonar_normalizer.scale.float()
 g = torch.Generator(device=dev).manual_seed(1234)
