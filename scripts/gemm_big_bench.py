@@ -5,7 +5,9 @@ import torch
 from lcm import _hip
 dev = torch.device("cuda:0")
 st = _hip.stream_ptr(dev)
-ITERS = 20
+ITERS = int(os.environ.get("GB_ITERS", "20"))
+NO_TORCH = bool(os.environ.get("GB_NO_TORCH"))       # under a counter-collecting profiler: only this library's kernels
+ROWS = [int(v) for v in os.environ.get("GB_ROWS", "256,1024,4096").split(",")]
 
 def bench(M, N, K, epi):
     A = torch.randn(M, K, device=dev).bfloat16()
@@ -23,15 +25,17 @@ def bench(M, N, K, epi):
     e1.record(); torch.cuda.synchronize()
     us = 1e3 * e0.elapsed_time(e1) / ITERS
     flops = 2.0 * M * N * K * (2 if epi == _hip.EPI_SWIGLU else 1)
-    ref = torch.nn.functional.linear(A, W)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(ITERS): torch.nn.functional.linear(A, W)
-    e1.record(); torch.cuda.synchronize()
-    us_t = 1e3 * e0.elapsed_time(e1) / ITERS
+    us_t = float("inf")
+    if not NO_TORCH:
+        torch.nn.functional.linear(A, W)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(ITERS): torch.nn.functional.linear(A, W)
+        e1.record(); torch.cuda.synchronize()
+        us_t = 1e3 * e0.elapsed_time(e1) / ITERS
     print(f"M={M:5d} N={N:5d} K={K:5d} epi={epi}  {us:8.1f} us  {flops / us / 1e6:7.1f} TFLOP/s   (torch/hipBLASLt linear: {2.0*M*N*K / us_t / 1e6:7.1f})", flush=True)
 
-for M in (256, 1024, 4096):
+for M in ROWS:
     bench(M, 2048, 2048, _hip.EPI_STORE)
     bench(M, 5632, 2048, _hip.EPI_SWIGLU)
     bench(M, 2048, 5632, _hip.EPI_STORE)
