@@ -295,6 +295,10 @@ int launch_denormalize_f32_out(const float* x0, const void* center, const void* 
 int launch_init_latents(const float* noise, float* lat, int64_t n, float sigma, float clip, hipStream_t st,
                         void* cast = nullptr, int dtype = LCMHIP_F32);
 // q/k/v (rows, d) T: rotate q in place, write rotated k and v into the cache rows given by cache_rows.
+// In-place LayerNorm / RMSNorm (norm_kind: LCMHIP_NORM_RMS or anything else = LayerNorm with optional bias) of `rows`
+// rows of x0 and, when x1 is given, of x1, both in the operand dtype.
+int launch_row_norm(void* x0, const void* w0, const void* b0, void* x1, const void* w1, const void* b1, int rows, int dim,
+                    int norm_kind, float eps, int dtype, hipStream_t st);
 int launch_rope_store(void* q, const void* k, const void* v, void* kc, void* vc, const int32_t* cache_rows,
                       const int32_t* positions, const float* cos_tab, const float* sin_tab, int rows, int d,
                       int cap, int use_rope, int dtype, hipStream_t st);

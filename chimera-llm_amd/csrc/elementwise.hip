@@ -1039,6 +1039,89 @@ int launch_finalize_step(const float* new_emb, void* seqs, int dtype, const int3
     return LCMHIP_OK;
 }
 
+// LayerNorm / RMSNorm of whole rows held in the operand dtype, in place: the q / k LayerNorm of
+// lcm/nn/transformer/attention.py:143-199 (over the full model dimension, before the head split).  Blocks [0, rows)
+// take the rows of x0, blocks [rows, 2 rows) those of x1 (its own parameters) when x1 is given.  dim <= 8192.
+template <typename T, int KIND>
+__global__ __launch_bounds__(256) void k_row_norm(T* __restrict__ x0, const T* __restrict__ w0, const T* __restrict__ b0,
+                                                  T* __restrict__ x1, const T* __restrict__ w1, const T* __restrict__ b1,
+                                                  int rows, int dim, float eps) {
+    __shared__ float red[4];
+    int r = blockIdx.x;
+    T* x = x0;
+    const T* w = w0;
+    const T* b = b0;
+    if (r >= rows) {
+        r -= rows; x = x1; w = w1; b = b1;
+    }
+    x += (size_t)r * dim;
+    float v[4][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (threadIdx.x + 256 * i) * 8;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[i][t] = 0.f;
+        if (c < dim) {
+            load8<T>(x + c, v[i]);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) s += KIND == LCMHIP_NORM_RMS ? v[i][t] * v[i][t] : v[i][t];
+        }
+    }
+    s = block_sum<4>(s, red);
+    float mean = 0.f, rstd;
+    if (KIND == LCMHIP_NORM_RMS) {
+        rstd = rsqrtf(s / dim + eps);
+    } else {
+        mean = s / dim;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = (threadIdx.x + 256 * i) * 8;
+            if (c < dim) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) q += (v[i][t] - mean) * (v[i][t] - mean);
+            }
+        }
+        q = block_sum<4>(q, red);
+        rstd = rsqrtf(q / dim + eps);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (threadIdx.x + 256 * i) * 8;
+        if (c < dim) {
+            float pw[8], pb[8];
+            load8<T>(w + c, pw);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) pb[t] = 0.f;
+            if (KIND == LCMHIP_NORM_LAYERNORM && b != nullptr) load8<T>(b + c, pb);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[i][t] = (v[i][t] - mean) * rstd * pw[t] + pb[t];
+            store8<T>(x + c, v[i]);
+        }
+    }
+}
+
+int launch_row_norm(void* x0, const void* w0, const void* b0, void* x1, const void* w1, const void* b1, int rows, int dim,
+                    int norm_kind, float eps, int dtype, hipStream_t st) {
+    LCM_REQUIRE(dim % 8 == 0 && dim <= 8192, "row norm: dim must be a multiple of 8 and <= 8192");
+    LCM_REQUIRE(x0 && w0 && (x1 == nullptr || w1 != nullptr), "row norm: rows and weights required");
+    if (rows <= 0) return LCMHIP_OK;
+    const dim3 grid(x1 ? 2 * rows : rows), block(256);
+#define LCM_RN(T, K) hipLaunchKernelGGL((k_row_norm<T, K>), grid, block, 0, st, (T*)x0, (const T*)w0, (const T*)b0, (T*)x1, \
+                                        (const T*)w1, (const T*)b1, rows, dim, eps)
+    if (dtype == LCMHIP_BF16) {
+        if (norm_kind == LCMHIP_NORM_RMS) LCM_RN(bf16_t, LCMHIP_NORM_RMS); else LCM_RN(bf16_t, LCMHIP_NORM_LAYERNORM);
+    } else if (dtype == LCMHIP_F32) {
+        if (norm_kind == LCMHIP_NORM_RMS) LCM_RN(float, LCMHIP_NORM_RMS); else LCM_RN(float, LCMHIP_NORM_LAYERNORM);
+    } else {
+        return fail(LCMHIP_ERR_INVALID, "row norm: unknown dtype");
+    }
+#undef LCM_RN
+    LCM_HIP_CHECK(hipGetLastError());
+    return LCMHIP_OK;
+}
+
 // q/k/v: (rows, d).  Rotates consecutive pairs (2i, 2i+1) of every 128-wide head of q (in place) and
 // k by the angle table row `positions[r]`, and scatters k, v to cache row `cache_rows[r]`.
 template <typename T>
@@ -1053,8 +1136,8 @@ __global__ __launch_bounds__(256) void k_rope_store(T* __restrict__ q, const T* 
     const int crow = cache_rows[r];
     const int pos = positions[r];
     for (int c = threadIdx.x * 8; c < d; c += blockDim.x * 8) {
-        float qv[8], kv[8], vv[8];
-        load8<T>(q + src + c, qv);
+        float qv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, kv[8], vv[8];
+        if (q != nullptr) load8<T>(q + src + c, qv);   // without q: a plain scatter of k / v rows into the cache
         load8<T>(k + src + c, kv);
         load8<T>(v + src + c, vv);
         if (use_rope) {
@@ -1068,7 +1151,7 @@ __global__ __launch_bounds__(256) void k_rope_store(T* __restrict__ q, const T* 
                 kv[2 * j] = k0 * cs - k1 * sn;
                 kv[2 * j + 1] = k0 * sn + k1 * cs;
             }
-            store8<T>(q + src + c, qv);
+            if (q != nullptr) store8<T>(q + src + c, qv);
         }
         const size_t dst = kv_cache_offset(crow, c, cap, d);   // 8 consecutive dims never straddle a head
         store8<T>(kc + dst, kv);

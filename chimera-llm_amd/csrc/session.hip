@@ -94,7 +94,7 @@ struct Tensor {
 };
 struct Lin { const void* w = nullptr; const void* b = nullptr; int out = 0, in = 0; };
 struct NormW { const void* w = nullptr; const void* b = nullptr; };
-struct AttnW { Lin q, k, v, o; };
+struct AttnW { Lin q, k, v, o; NormW qn, kn; };   // qn / kn: optional q / k LayerNorm (attention.py:143-199)
 struct FfnW { Lin gate, inner, out; };
 struct CtxLayer { NormW sa_norm, ffn_norm; AttnW sa; FfnW ffn; };
 struct DenLayer { NormW sa_norm, ca_norm, ffn_norm; AttnW sa, ca; FfnW ffn; Lin mod; Lin ov; };   // ov: optional folded output_proj * v_proj
@@ -159,7 +159,13 @@ static int get_norm(lcmhip_model* m, const std::string& prefix, int d, int kind,
 // Kernel family of a norm style: everything but RMS is a LayerNorm whose absent parameters are 1 / 0.
 static inline int kernel_norm_kind(int kind) { return kind == LCMHIP_NORM_RMS ? LCMHIP_NORM_RMS : LCMHIP_NORM_LAYERNORM; }
 
-static int get_attn(lcmhip_model* m, const std::string& p, int d, bool out_bias, AttnW* a) {
+static int get_attn(lcmhip_model* m, const std::string& p, int d, const lcmhip_tower_desc& t, AttnW* a) {
+    const bool out_bias = t.out_proj_bias != 0;
+    a->qn = a->kn = NormW{};
+    if (t.qk_layernorm) {
+        LCM_TRY(get_norm(m, p + ".q_layer_norm", d, t.norm_kind, &a->qn));
+        LCM_TRY(get_norm(m, p + ".k_layer_norm", d, t.norm_kind, &a->kn));
+    }
     LCM_TRY(get_lin(m, p + ".q_proj", d, d, true, &a->q));
     LCM_TRY(get_lin(m, p + ".k_proj", d, d, true, &a->k));
     LCM_TRY(get_lin(m, p + ".v_proj", d, d, true, &a->v));
@@ -519,6 +525,18 @@ static int norm(lcmhip_session* s, const char* tag, float* x, const NormW& w, co
                                 kernel_norm_kind(kind), d.norm_eps, d.dtype, pend, st, steps);
 }
 
+// q / k LayerNorm of an attention block, in place on projected rows (either pointer may be null).
+static int qk_norm(lcmhip_session* s, const char* tag, const lcmhip_tower_desc& t, const AttnW& a, void* q, void* k, int rows,
+                   hipStream_t st) {
+    const lcmhip_model_desc& d = s->model->desc;
+    const NormW* n0 = q ? &a.qn : &a.kn;
+    void* x0 = q ? q : k;
+    void* x1 = q ? k : nullptr;
+    ProfScope ps(&s->prof, tag, (q && k ? 4.0 : 2.0) * rows * d.model_dim * (double)dtype_size(d.dtype), 0.0, st);
+    return launch_row_norm(x0, n0->w ? n0->w : s->ones, n0->b, x1, a.kn.w ? a.kn.w : s->ones, a.kn.b, rows, d.model_dim,
+                           kernel_norm_kind(t.norm_kind), d.norm_eps, d.dtype, st);
+}
+
 static int ffn_in(lcmhip_session* s, const char* tag, const lcmhip_tower_desc& t, const FfnW& f, const void* a, int rows,
                   hipStream_t st) {
     const int d = s->model->desc.model_dim;
@@ -605,7 +623,7 @@ int lcmhip_model_finalize(lcmhip_model* m) {
         CtxLayer& L = m->ctx[i];
         LCM_TRY(get_norm(m, p + ".self_attn_layer_norm", dm, d.context.norm_kind, &L.sa_norm));
         LCM_TRY(get_norm(m, p + ".ffn_layer_norm", dm, d.context.norm_kind, &L.ffn_norm));
-        LCM_TRY(get_attn(m, p + ".self_attn", dm, d.context.out_proj_bias != 0, &L.sa));
+        LCM_TRY(get_attn(m, p + ".self_attn", dm, d.context, &L.sa));
         LCM_TRY(get_ffn(m, p + ".ffn", dm, d.context, &L.ffn));
     }
     LCM_TRY(get_norm(m, dec + ".layer_norm", dm, d.context.norm_kind, &m->ctx_final));
@@ -626,8 +644,8 @@ int lcmhip_model_finalize(lcmhip_model* m) {
         LCM_TRY(get_norm(m, p + ".self_attn_layer_norm", dm, d.denoiser.norm_kind, &L.sa_norm));
         LCM_TRY(get_norm(m, p + ".cross_attention_layer_norm", dm, d.denoiser.norm_kind, &L.ca_norm));
         LCM_TRY(get_norm(m, p + ".ffn_layer_norm", dm, d.denoiser.norm_kind, &L.ffn_norm));
-        LCM_TRY(get_attn(m, p + ".self_attn", dm, d.denoiser.out_proj_bias != 0, &L.sa));
-        LCM_TRY(get_attn(m, p + ".cross_attention", dm, d.denoiser.out_proj_bias != 0, &L.ca));
+        LCM_TRY(get_attn(m, p + ".self_attn", dm, d.denoiser, &L.sa));
+        LCM_TRY(get_attn(m, p + ".cross_attention", dm, d.denoiser, &L.ca));
         LCM_TRY(get_ffn(m, p + ".ffn", dm, d.denoiser, &L.ffn));
         LCM_TRY(get_lin(m, p + ".modulator.fc", 9 * dm, dm, true, &L.mod));
         // optional derived weight: self-attention over one position is output_proj(v_proj(h)) = h W_ov^T + b_ov
@@ -740,7 +758,13 @@ int lcmhip_session_reset(lcmhip_session* s, int32_t n_docs, void* stream) {
     const size_t es = dtype_size(d.dtype);
     const size_t layer_bytes = (size_t)s->max_batch * (s->cap + 1) * d.model_dim * es;
     for (int l = 0; l < d.denoiser.num_layers; ++l) {
-        LCM_TRY(launch_fill_rows(s->cross_k + l * layer_bytes, m->den[l].ca.k.b, s->slot0_rows, n_docs, d.model_dim,
+        const void* k0 = m->den[l].ca.k.b;
+        if (d.denoiser.qk_layernorm) {   // the zero vector's key is k_layer_norm(k_proj(0)) = k_layer_norm(b_k)
+            LCM_HIP_CHECK(hipMemcpyAsync(s->act_k, k0, (size_t)d.model_dim * es, hipMemcpyDeviceToDevice, st));
+            LCM_TRY(qk_norm(s, "ctx.qk_norm", d.denoiser, m->den[l].ca, nullptr, s->act_k, 1, st));
+            k0 = s->act_k;
+        }
+        LCM_TRY(launch_fill_rows(s->cross_k + l * layer_bytes, k0, s->slot0_rows, n_docs, d.model_dim,
                                  s->cap + 1, d.dtype, st));
         LCM_TRY(launch_fill_rows(s->cross_v + l * layer_bytes, m->den[l].ca.v.b, s->slot0_rows, n_docs, d.model_dim,
                                  s->cap + 1, d.dtype, st));
@@ -911,6 +935,7 @@ static int append_impl(lcmhip_session* s, const float* x, int32_t n_tokens, int3
                     void* const o3[3] = {s->act_q, s->act_k, s->act_v};
                     LCM_TRY(gemm_stack(s, "ctx.qkv", s->act_a, dm, 3, w3, o3, dm, R, st));
                 }
+                if (tc.qk_layernorm) LCM_TRY(qk_norm(s, "ctx.qk_norm", tc, L.sa, s->act_q, s->act_k, R, st));
                 {
                     ProfScope ps(&s->prof, "ctx.rope_store", 5.0 * R * dm * es, 0.0, st);
                     LCM_TRY(launch_rope_store(s->act_q, s->act_k, s->act_v, s->self_k + l * self_layer, s->self_v + l * self_layer,
@@ -931,6 +956,15 @@ static int append_impl(lcmhip_session* s, const float* x, int32_t n_tokens, int3
             // cross-attention keys / values of the new context positions, every denoiser layer
             for (int l = 0; l < d.denoiser.num_layers; ++l) {
                 const Lin* const w2[2] = {&m->den[l].ca.k, &m->den[l].ca.v};
+                if (d.denoiser.qk_layernorm) {
+                    // k passes through its LayerNorm before it is cached: project into plain rows, normalize, scatter
+                    void* const o2[2] = {s->act_k, s->act_v};
+                    LCM_TRY(gemm_stack(s, "ctx.cross_kv", s->act_a, dm, 2, w2, o2, dm, R, st));
+                    LCM_TRY(qk_norm(s, "ctx.qk_norm", d.denoiser, m->den[l].ca, nullptr, s->act_k, R, st));
+                    LCM_TRY(launch_rope_store(nullptr, s->act_k, s->act_v, s->cross_k + l * cross_layer, s->cross_v + l * cross_layer,
+                                              s->cross_rows, s->pos_rows, s->rope_cos, s->rope_sin, R, dm, s->cap + 1, 0, d.dtype, st));
+                    continue;
+                }
                 void* const o2[2] = {s->cross_k + l * cross_layer, s->cross_v + l * cross_layer};
                 LCM_TRY(gemm_stack(s, "ctx.cross_kv", s->act_a, dm, 2, w2, o2, dm, R, st, s->cross_rows, s->cap + 1));
             }
@@ -1032,9 +1066,16 @@ static int denoise_body(lcmhip_session* s, const float* noise, float* out, float
             // see the zero slot, whose value is a per-layer constant
             LCM_TRY(norm(s, "den.norm_mod", s->xres, Ly.ca_norm, mod + 3 * dm, mod + 4 * dm, s->act_a, rows, B, td.norm_kind, &pend, st));
             Pending qp;   // the q projection stays in slab_q; the attention kernel sums it
-            LCM_TRY(gemm_pending(s, "den.cross_q", s->act_a, dm, Ly.ca.q, nullptr, B, &qp, st, s->slab_q));
+            if (td.qk_layernorm) {
+                // q passes through its LayerNorm first: a finished product, normalized in place
+                LCM_TRY(gemm(s, "den.cross_q", s->act_a, dm, Ly.ca.q, nullptr, nullptr, s->act_q, dm, B, LCMHIP_EPI_STORE, st));
+                LCM_TRY(qk_norm(s, "den.qk_norm", td, Ly.ca, s->act_q, nullptr, B, st));
+            } else {
+                LCM_TRY(gemm_pending(s, "den.cross_q", s->act_a, dm, Ly.ca.q, nullptr, B, &qp, st, s->slab_q));
+            }
             {
                 AttnQ qa{};
+                if (td.qk_layernorm) qa.q = s->act_q;
                 qa.partial = qp.partial; qa.splits = qp.splits; qa.rows = B; qa.bias = qp.bias;
                 ProfScope ps(&s->prof, "den.cross_attn", 2.0 * B * (double)nkeys * dm * es + B * dm * (es + 4.0 * qp.splits),
                              4.0 * B * (double)nkeys * dm, st);
@@ -1214,6 +1255,7 @@ int lcmhip_denoise_positions(lcmhip_session* s, const float* noisy, const int32_
                 }
                 LCM_TRY(norm(s, "pos.norm_mod", s->xres, Ly.ca_norm, mod + 3 * dm, mod + 4 * dm, s->act_a, R, R, td.norm_kind, nullptr, st, &rs));
                 LCM_TRY(gemm(s, "pos.cross_q", s->act_a, dm, Ly.ca.q, nullptr, nullptr, s->act_q, dm, R, LCMHIP_EPI_STORE, st));
+                if (td.qk_layernorm) LCM_TRY(qk_norm(s, "pos.qk_norm", td, Ly.ca, s->act_q, nullptr, R, st));
                 {
                     AttnQ qa{};
                     qa.q = s->act_q;

@@ -39,7 +39,7 @@ EXPORTS = [
 class TowerDesc(C.Structure):
     _fields_ = [("num_layers", C.c_int32), ("num_heads", C.c_int32), ("ffn_dim", C.c_int32),
                 ("norm_kind", C.c_int32), ("ffn_kind", C.c_int32), ("pos_kind", C.c_int32),
-                ("out_proj_bias", C.c_int32), ("rope_theta", C.c_float)]
+                ("out_proj_bias", C.c_int32), ("rope_theta", C.c_float), ("qk_layernorm", C.c_int32)]
 
 
 class ModelDesc(C.Structure):

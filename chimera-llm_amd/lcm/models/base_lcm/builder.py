@@ -94,6 +94,9 @@ def parameter_spec(config: BaseLCModelConfig,
         spec.append((f"{p}.self_attn.output_proj.weight", (d, d), "matrix"))
         if tc.mha_output_proj_bias:
             spec.append((f"{p}.self_attn.output_proj.bias", (d,), "zeros"))
+        if tc.enable_qk_layernorm:       # lcm/nn/transformer/attention.py:131-141
+            norm(f"{p}.self_attn.q_layer_norm")
+            norm(f"{p}.self_attn.k_layer_norm")
         if tc.use_swiglu:
             spec.append((f"{p}.ffn.gate_proj.weight", (F, d), "matrix"))
             spec.append((f"{p}.ffn.gate_proj.bias", (F,), "zeros"))
@@ -191,7 +194,7 @@ class BaseLCModel(AbstractLCModel):
             norm_kind=_NORM_KIND[tc.layer_normalization_style],
             ffn_kind=_hip.FFN_SWIGLU if tc.use_swiglu else _hip.FFN_RELU,
             pos_kind=_POS_KIND[tc.pos_embedding_style], out_proj_bias=int(tc.mha_output_proj_bias),
-            rope_theta=float(tc.rope_theta))
+            rope_theta=float(tc.rope_theta), qk_layernorm=int(tc.enable_qk_layernorm))
         none = _hip.TowerDesc(num_layers=0)      # no denoiser tower: selects the base LCM in the library
         desc = _hip.ModelDesc(sonar_dim=c.sonar_embed_dim, model_dim=c.model_dim, max_seq_len=c.max_seq_len,
                               timestep_freq_dim=TIMESTEP_FREQ_DIM, dtype=_hip.dtype_code(self.dtype), norm_eps=1e-5,

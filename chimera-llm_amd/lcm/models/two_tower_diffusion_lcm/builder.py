@@ -70,8 +70,8 @@ def _check_supported(name: str, tc: TransformerConfig) -> None:
         bad.append("only pre-norm stacks")
     if tc.pos_embedding_style not in _POS_KIND:
         bad.append(f"pos_embedding_style={tc.pos_embedding_style}")
-    if tc.enable_qk_layernorm or tc.mha_qkv_weight_normalization or tc.mha_output_weight_normalization:
-        bad.append("qk-layernorm / weight-norm")
+    if tc.mha_qkv_weight_normalization or tc.mha_output_weight_normalization:
+        bad.append("weight-norm parametrization of the attention projections")
     if tc.scale_residual is not None:
         bad.append("scale_residual")
     if not tc.use_swiglu and tc.ffn_inner_activation_name != "relu":
@@ -141,6 +141,9 @@ def parameter_spec(config: TwoTowerDiffusionLCModelConfig,
                 spec.append((f"{p}.{attn}.output_proj.weight", (d, d), "matrix"))
                 if tc.mha_output_proj_bias:
                     spec.append((f"{p}.{attn}.output_proj.bias", (d,), "zeros"))
+                if tc.enable_qk_layernorm:       # lcm/nn/transformer/attention.py:131-141
+                    norm(f"{p}.{attn}.q_layer_norm")
+                    norm(f"{p}.{attn}.k_layer_norm")
             if tc.use_swiglu:
                 spec.append((f"{p}.ffn.gate_proj.weight", (F, d), "matrix"))
                 spec.append((f"{p}.ffn.gate_proj.bias", (F,), "zeros"))
@@ -479,7 +482,7 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
                 norm_kind=_NORM_KIND[tc.layer_normalization_style],
                 ffn_kind=_hip.FFN_SWIGLU if tc.use_swiglu else _hip.FFN_RELU,
                 pos_kind=_POS_KIND[tc.pos_embedding_style], out_proj_bias=int(tc.mha_output_proj_bias),
-                rope_theta=float(tc.rope_theta))
+                rope_theta=float(tc.rope_theta), qk_layernorm=int(tc.enable_qk_layernorm))
 
         desc = _hip.ModelDesc(sonar_dim=c.sonar_embed_dim, model_dim=c.model_dim, max_seq_len=c.max_seq_len,
                               timestep_freq_dim=TIMESTEP_FREQ_DIM, dtype=_hip.dtype_code(self.dtype), norm_eps=1e-5,

@@ -64,6 +64,9 @@ typedef struct {
     int32_t pos_kind;      /* LCMHIP_POS_*  */
     int32_t out_proj_bias; /* 0 / 1 */
     float rope_theta;
+    int32_t qk_layernorm;  /* 0 / 1: LayerNorm (the tower's norm style, full model_dim) on q and on k after their
+                              projections, before the head split and RoPE; lcm/nn/transformer/attention.py:143-199.
+                              Tensors <attn>.q_layer_norm.* and <attn>.k_layer_norm.* */
 } lcmhip_tower_desc;
 
 /* lcm/models/two_tower_diffusion_lcm/builder.py:49-81 (TwoTowerDiffusionLCModelConfig). */

@@ -26,6 +26,7 @@ class TowerConfig:
     pos: str = "learned"               # "learned" | "rope" | "none"
     rope_theta: float = 10000.0
     out_proj_bias: bool = False
+    qk_layernorm: bool = False         # LayerNorm on q and k after their projections (attention.py:143-199)
 
     def ffn_dim(self) -> int:
         return glu_inner_dim(self.ffn_inner_dim) if self.use_swiglu else self.ffn_inner_dim

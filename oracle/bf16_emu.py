@@ -203,6 +203,7 @@ class _Bf16Blocks:
 class OracleTwoTowerBf16(_Bf16Blocks, OracleTwoTower):
     def __init__(self, cfg, sd: Dict[str, Tensor]):
         OracleTwoTower.__init__(self, cfg, {k: r16(v.float()) for k, v in sd.items()})
+        assert not (cfg.context.qk_layernorm or cfg.denoiser.qk_layernorm), "the bf16 emulation does not model q / k LayerNorm"
         sd = self.sd
         self.ov: List[Tuple[Tensor, Tensor]] = []
         self.uconst: List[Tensor] = []
@@ -311,6 +312,7 @@ class OracleTwoTowerBf16(_Bf16Blocks, OracleTwoTower):
 class OracleBaseLCMBf16(_Bf16Blocks, OracleBaseLCM):
     def __init__(self, cfg, sd: Dict[str, Tensor]):
         OracleBaseLCM.__init__(self, cfg, {k: r16(v.float()) for k, v in sd.items()})
+        assert not cfg.lcm.qk_layernorm, "the bf16 emulation does not model q / k LayerNorm"
 
     def normalize(self, x: Tensor) -> Tensor:
         if not self.has_normalizer:

@@ -166,12 +166,19 @@ class OracleTwoTower:
              cache: Optional[KVCache] = None, layer: int = -1, use_rope: bool = False) -> Tensor:
         """lcm/nn/transformer/attention.py:201-298."""
         sd, H = self.sd, tc.num_heads
-        q = linear(x_q, sd, prefix + ".q_proj").unflatten(-1, (H, -1)).transpose(1, 2)
+        qk_ln = getattr(tc, "qk_layernorm", False)          # attention.py:151-155, 178-182: before the head split
+        q = linear(x_q, sd, prefix + ".q_proj")
+        if qk_ln:
+            q = norm(q, sd, prefix + ".q_layer_norm", tc.norm, self.cfg.norm_eps)
+        q = q.unflatten(-1, (H, -1)).transpose(1, 2)
         memo = getattr(self, "_kv_memo", None) if x_kv is not x_q else None
         if memo is not None and prefix in memo:
             k, v = memo[prefix]
         else:
-            k = linear(x_kv, sd, prefix + ".k_proj").unflatten(-1, (H, -1)).transpose(1, 2)
+            k = linear(x_kv, sd, prefix + ".k_proj")
+            if qk_ln:
+                k = norm(k, sd, prefix + ".k_layer_norm", tc.norm, self.cfg.norm_eps)
+            k = k.unflatten(-1, (H, -1)).transpose(1, 2)
             v = linear(x_kv, sd, prefix + ".v_proj").unflatten(-1, (H, -1)).transpose(1, 2)
             if memo is not None:
                 memo[prefix] = (k, v)

@@ -62,6 +62,12 @@ def _tower_shapes(prefix: str, d: int, tc: TowerConfig, cross: bool, modulator: 
             yield f"{p}.{attn}.output_proj.weight", (d, d), "w"
             if tc.out_proj_bias:
                 yield f"{p}.{attn}.output_proj.bias", (d,), "b"
+            if tc.qk_layernorm:              # attention.py:131-141: the tower's own norm style over model_dim
+                for n in ("q_layer_norm", "k_layer_norm"):
+                    if tc.norm != "unit":
+                        yield f"{p}.{attn}.{n}.weight", (d,), "norm_w"
+                    if tc.norm == "standard":
+                        yield f"{p}.{attn}.{n}.bias", (d,), "norm_b"
         if tc.use_swiglu:
             yield f"{p}.ffn.gate_proj.weight", (F, d), "w"
             yield f"{p}.ffn.gate_proj.bias", (F,), "b"

@@ -113,3 +113,32 @@ def test_batch_equals_singles_and_ragged_eos():
         one, _ = run_hip_base(arch, sd, x[i:i + 1], nz[:, i:i + 1], 3, opts, model=model)
         a, b = one.hypotheses[0][0].seq, full.hypotheses[i][0].seq
         assert (a - b).abs().max() <= 1e-6 * max(1.0, float(b.abs().max()))
+
+
+def test_base_qk_layernorm_forward_and_generation():
+    """`enable_qk_layernorm` on the base LCM's decoder (lcm/nn/transformer/attention.py:143-199; RMSNorm style, RoPE
+    after the norms): the whole-sequence forward (many-row kernels) and cached generation against the oracle, fp32."""
+    from lcm.datasets.batch import EmbeddingsBatch
+    from lcm.models.base_lcm import create_base_lcm_model
+    from oracle.weights import synthetic_noise, synthetic_prompts
+    arch = "mini_base_lcm"
+    cfg = oracle.get_base_arch(arch)
+    cfg.lcm.qk_layernorm = True
+    sd = oracle.init_state_dict(cfg, seed=3, qk_gain=2.0, norm_jitter=0.2)
+    assert "lcm.layers.0.self_attn.k_layer_norm.weight" in sd
+    mc = base_config(arch)
+    mc.lcm.enable_qk_layernorm = True
+    model = create_base_lcm_model(mc, device="cuda:0", dtype=torch.float32)
+    assert set(model.state_dict()) == set(sd)
+    model.load_state_dict(sd)
+    x = synthetic_prompts(oracle.load_dummy_normalizer(), 5, 90, seed=77)
+    ref = oracle.OracleBaseLCM(cfg, sd).predict(x)
+    out = model.predict_next_sentence(EmbeddingsBatch(x.cuda(), None)).seqs.cpu()
+    assert (out - ref).abs().max() <= 2e-4 * ref.abs().max()
+    assert torch.nn.functional.cosine_similarity(out, ref, dim=-1).min() >= FP32_COS
+    nz = synthetic_noise(8, 5, seed=78)
+    opts = dict(OPTS, lcm_temperature=0.5)
+    ref_g = run_oracle_base(cfg, sd, x[:, :4], nz, 4, opts)
+    out_g, _ = run_hip_base(arch, sd, x[:, :4], nz, 4, opts, model=model)
+    worst, cos = compare(out_g.hypotheses, ref_g, _norm_sd(sd), start=4)
+    assert worst <= FP32_MAX_ABS and cos >= FP32_COS, (worst, cos)

@@ -111,6 +111,49 @@ def test_layer_norm_styles(ctx_norm, den_norm, dtype):
         assert cos >= BF16_COS, (worst, cos)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ctx_norm,den_norm", [("rms", "rms"), ("standard", "unit")])
+def test_qk_layernorm(ctx_norm, den_norm, dtype):
+    """`enable_qk_layernorm` (lcm/nn/transformer/attention.py:143-199): q and k pass through a LayerNorm of the tower's
+    style over the whole model dimension before the head split and RoPE -- in the contextualizer's self-attention and in
+    the denoiser's cross-attention, where the prepended zero vector's key becomes k_layer_norm(b_k).  Ragged prompts,
+    guidance on (the unconditional rows see only that zero slot)."""
+    cfg = O.get_arch(ARCH)
+    cfg.context.norm, cfg.denoiser.norm = ctx_norm, den_norm
+    cfg.context.qk_layernorm = cfg.denoiser.qk_layernorm = True
+    sd = O.init_state_dict(cfg, seed=6, mod_gain=4.0, qk_gain=1.5, norm_jitter=0.2)
+    assert "context_encoder.layers.0.self_attn.q_layer_norm.weight" in sd
+    assert ("denoiser.layers.0.cross_attention.k_layer_norm.weight" in sd) == (den_norm != "unit")
+    from oracle.weights import synthetic_noise, synthetic_prompts
+    norm = {"center": sd["sonar_normalizer.center"], "scale": sd["sonar_normalizer.scale"]}
+    lens = [4, 2, 3]
+    x, nz = synthetic_prompts(norm, 3, 4, seed=19), synthetic_noise(7, 3, seed=20)
+    opts = dict(DEFAULT_OPTS, inference_timesteps=10, guidance_scale=2.0)
+    if dtype == torch.bfloat16:
+        sd = {k: O.r16(v) for k, v in sd.items()}
+        x = O.r16(x)
+    gen = O.OracleGenerator(O.OracleTwoTower(cfg, sd), O.GenOptions(**opts))
+    ref = gen(x, prompt_lens=torch.tensor(lens), max_gen_len=3, noise=nz)
+    from lcm.models.two_tower_diffusion_lcm import create_two_tower_diffusion_lcm_model
+    mc = mini_config()
+    mc.context_encoder.layer_normalization_style, mc.denoiser.layer_normalization_style = ctx_norm, den_norm
+    mc.context_encoder.enable_qk_layernorm = mc.denoiser.enable_qk_layernorm = True
+    model = create_two_tower_diffusion_lcm_model(mc, device="cuda:0", dtype=dtype)
+    assert set(model.state_dict()) == set(sd)
+    model.load_state_dict(sd)
+    out = _hip_generate(model, x, nz, 3, opts, prompt_lens=lens)
+    worst, cos = compare(out.hypotheses, ref, sd)
+    if dtype == torch.float32:
+        assert worst <= FP32_MAX_ABS and cos >= FP32_COS, (worst, cos)
+        # the norms matter on this problem: the same weights without them give other sentences
+        cfg.context.qk_layernorm = cfg.denoiser.qk_layernorm = False
+        plain = O.OracleGenerator(O.OracleTwoTower(cfg, sd), O.GenOptions(**opts))(x, prompt_lens=torch.tensor(lens), max_gen_len=3, noise=nz)
+        w_plain, _ = compare(out.hypotheses, plain, sd)
+        assert w_plain > 10 * FP32_MAX_ABS, w_plain
+    else:
+        assert cos >= BF16_COS, (worst, cos)
+
+
 def test_clipping_normalizer(tmp_path):
     """A model whose `sonar_normalizer_name` points to a card of the `clipping` arch clamps in normalize (after
     centring / scaling) and in denormalize (before scaling back), inside the fused session kernels too."""

@@ -155,3 +155,27 @@ def test_norm_styles_and_clipping_normalizer_shape_the_parameter_table():
                    "checkpoint": None})
     with pytest.raises(NotImplementedError):
         normalizer_config_for("host_test_fft_normalizer", 1024)
+
+
+def test_qk_layernorm_adds_its_norms_to_the_parameter_table():
+    """`enable_qk_layernorm` (lcm/nn/transformer/attention.py:131-141): every attention block gains q_layer_norm and
+    k_layer_norm of the tower's norm style; the table equals the oracle's, two-tower and base."""
+    from lcm.models.base_lcm.builder import parameter_spec as base_parameter_spec
+    from lcm.models.two_tower_diffusion_lcm.builder import parameter_spec
+    from oracle.weights import base_state_dict_spec
+    from parity_utils import base_config, mini_config
+    cfg = mini_config()
+    cfg.context_encoder.enable_qk_layernorm = cfg.denoiser.enable_qk_layernorm = True
+    cfg.denoiser.layer_normalization_style = "standard"
+    names = {n for n, _, _ in parameter_spec(cfg)}
+    assert {"context_encoder.layers.0.self_attn.q_layer_norm.weight", "denoiser.layers.1.cross_attention.k_layer_norm.bias",
+            "denoiser.layers.1.self_attn.q_layer_norm.weight"} <= names
+    ocfg = oracle.get_arch("mini_two_tower_diffusion_lcm")
+    ocfg.context.qk_layernorm = ocfg.denoiser.qk_layernorm = True
+    ocfg.denoiser.norm = "standard"
+    assert names == {n for n, _, _ in state_dict_spec(ocfg)}
+    bcfg = base_config("mini_base_lcm")
+    bcfg.lcm.enable_qk_layernorm = True
+    obase = oracle.get_base_arch("mini_base_lcm")
+    obase.lcm.qk_layernorm = True
+    assert {n for n, _, _ in base_parameter_spec(bcfg)} == {n for n, _, _ in base_state_dict_spec(obase)}
