@@ -549,7 +549,7 @@ bool gemm_big_applicable(const GemmArgs& a, bool may_split) {
 // for its waves of tiles.  A full wave of 256 x 256 tiles takes about 1.6 x a full wave of 128 x 128 tiles (measured
 // on the SwiGLU projection: 50-56 us against 32-34 us; four times the work at 1.15-1.2 x the rate), and a partly
 // filled last wave takes as long as a full one: at 1024 rows 176 tiles in one wave take 56 us against 67 us for 704
-// tiles of 128 x 128 in two.  No K split, 32-bit operand offsets.  LCMHIP_BIG256_MIN_TILES > 0 replaces the estimate
+// tiles of 128 x 128 in two.  The ratio differs between devices of the pool (see below).  No K split, 32-bit operand offsets.  LCMHIP_BIG256_MIN_TILES > 0 replaces the estimate
 // by a plain tile count.
 static bool big256_applicable(const GemmArgs& a, int epi, int splits, int m_rows) {
     static const int mode = [] { const char* e = getenv("LCMHIP_BIG256"); return e ? atoi(e) : 1; }();
@@ -563,7 +563,11 @@ static bool big256_applicable(const GemmArgs& a, int epi, int splits, int m_rows
     if (min_tiles > 0) return tiles >= min_tiles;
     const int tiles128 = (wrows / kBN) * ((m_rows + kBM - 1) / kBM);
     const int waves256 = (tiles + 255) / 256, waves128 = (tiles128 + 511) / 512;
-    return 16 * waves256 < 10 * waves128;
+    // wave-time ratio in tenths (LCMHIP_BIG256_RATIO overrides): the stacked q / k / v product of 4096 rows (384 tiles
+    // in 2 waves against 1536 in 3) measured 2 % faster at 1.3 on a slower device of the pool: too little to move the
+    // routing the batch sweep was tuned with
+    static const int ratio10 = [] { const char* e = getenv("LCMHIP_BIG256_RATIO"); return e ? atoi(e) : 16; }();
+    return ratio10 * waves256 < 10 * waves128;
 }
 
 static int launch_gemm_big256(const GemmArgs& a_in, int epi, int m_rows, hipStream_t st) {
