@@ -112,6 +112,7 @@ struct lcmhip_model {
     lcmhip::Lin pre_linear, t_fc1, t_fc2, init_proj, final_proj, postnet;
     bool base = false;          // base LCM: frontend -> causal decoder -> postnet, no denoiser tower
     const void* pos_table = nullptr;
+    const void* den_pos_table = nullptr;   // learned positions of the denoiser's latents (lcm_denoiser.py:211-212), optional
     std::vector<lcmhip::CtxLayer> ctx;
     std::vector<lcmhip::DenLayer> den;
     lcmhip::NormW ctx_final, den_final;
@@ -199,6 +200,7 @@ struct lcmhip_session {
     lcmhip_model* model = nullptr;
     int max_batch = 0, cap = 0, max_steps = 0, rows_cap = 0, chunk_rows = 0;
     bool keep_context = false;
+    char* init_bias_pos = nullptr;  // initial_proj bias + position 0 of the denoiser's learned positions (operand dtype)
     bool stack_products = true;     // q / k / v (and cross k / v) of many rows in one launch; LCMHIP_STACK=0 turns it off
     // carved device buffers
     int32_t *slot_map = nullptr, *pos_rows = nullptr, *self_rows = nullptr, *cross_rows = nullptr, *slot0_rows = nullptr;
@@ -289,6 +291,7 @@ static size_t carve(lcmhip_session* s, char* base) {
     s->slab_q = c.take<float>(s->slab_bytes);
     s->d_cross_keys = c.take<int32_t>(256);
     s->ones = c.take<char>(dm * es);
+    s->init_bias_pos = c.take<char>(dm * es);
     s->noise_buf = c.take<float>(B * D * 4);
     s->out_buf = c.take<float>(B * D * 4);
     return c.off;
@@ -310,6 +313,19 @@ __global__ void k_make_rows(const int32_t* __restrict__ slot_map, int32_t* pos, 
 }
 
 __global__ void k_set_int(int32_t* p, int32_t v) { *p = v; }
+
+// pos[r] = j0 + r % sc: the position of row r inside its document (rows = documents x sc positions)
+__global__ void k_row_positions(int32_t* __restrict__ pos, int rows, int sc, int j0) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < rows) pos[r] = j0 + r % sc;
+}
+
+// out[i] = a[i] + b[i] in the operand dtype (a may be null = 0)
+template <typename T>
+__global__ void k_vec_add(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) Elem<T>::store(out + i, (a ? Elem<T>::load(a + i) : 0.f) + Elem<T>::load(b + i));
+}
 
 __global__ void k_add_int(const int32_t* __restrict__ src, int32_t* __restrict__ dst, int n, int add) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -565,8 +581,8 @@ int lcmhip_model_create(const lcmhip_model_desc* desc, lcmhip_model** out) {
     const bool base = desc->denoiser.num_layers == 0;   // base LCM: no denoiser tower
     if (!base) {
         LCM_TRY(check_tower(desc->denoiser, desc->model_dim, "denoiser"));
-        if (desc->denoiser.pos_kind != LCMHIP_POS_NONE)
-            return fail(LCMHIP_ERR_UNSUPPORTED, "denoiser positional encoders are not implemented (reference archs use none)");
+        if (desc->denoiser.pos_kind != LCMHIP_POS_NONE && desc->denoiser.pos_kind != LCMHIP_POS_LEARNED)
+            return fail(LCMHIP_ERR_UNSUPPORTED, "denoiser: only learned positions (or none) are implemented for the latents");
     }
     LCM_REQUIRE(desc->embed_scale >= 0.f, "model_create: embed_scale");
     auto* m = new lcmhip_model();
@@ -637,6 +653,14 @@ int lcmhip_model_finalize(lcmhip_model* m) {
     LCM_TRY(get_lin(m, "denoiser.embed_time.fc2", dm, dm, true, &m->t_fc2));
     LCM_TRY(get_lin(m, "denoiser.initial_proj.fc", dm, D, true, &m->init_proj));
     LCM_TRY(get_lin(m, "denoiser.final_proj.fc", D, dm, true, &m->final_proj));
+    m->den_pos_table = nullptr;
+    if (d.denoiser.pos_kind == LCMHIP_POS_LEARNED) {   // factory.py:187-209 builds it, lcm_denoiser.py:211-212 adds it
+        auto t = m->tensors.find("denoiser.pos_encoder.weight");
+        if (t == m->tensors.end()) return fail(LCMHIP_ERR_STATE, "missing weight: denoiser.pos_encoder.weight");
+        LCM_REQUIRE(t->second.shape.size() == 2 && t->second.shape[0] >= d.max_seq_len && t->second.shape[1] == dm,
+                    "bad shape for denoiser.pos_encoder.weight");
+        m->den_pos_table = t->second.ptr;
+    }
     m->den.assign(d.denoiser.num_layers, DenLayer{});
     for (int i = 0; i < d.denoiser.num_layers; ++i) {
         const std::string p = "denoiser.layers." + std::to_string(i);
@@ -874,6 +898,16 @@ int lcmhip_session_set_schedule(lcmhip_session* s, const int32_t* timesteps, int
     for (int l = 0; l < L; ++l)
         LCM_TRY(gemm(s, "setup", m->den[l].ca.v.b, dm, m->den[l].ca.o, nullptr, nullptr, s->uconst + (size_t)l * dm, dm,
                      1, LCMHIP_EPI_STORE_F32, st));
+    // ---- learned positions of the latents: the sampling loop's single latent sits at position 0
+    if (m->den_pos_table) {
+        if (d.dtype == LCMHIP_BF16)
+            hipLaunchKernelGGL((k_vec_add<bf16_t>), dim3((dm + 255) / 256), dim3(256), 0, st, (const bf16_t*)m->init_proj.b,
+                               (const bf16_t*)m->den_pos_table, (bf16_t*)s->init_bias_pos, dm);
+        else
+            hipLaunchKernelGGL((k_vec_add<float>), dim3((dm + 255) / 256), dim3(256), 0, st, (const float*)m->init_proj.b,
+                               (const float*)m->den_pos_table, (float*)s->init_bias_pos, dm);
+        LCM_HIP_CHECK(hipGetLastError());
+    }
     LCM_HIP_CHECK(hipStreamSynchronize(st));
     s->have_schedule = true;
     return LCMHIP_OK;
@@ -1051,6 +1085,8 @@ static int denoise_body(lcmhip_session* s, const float* noise, float* out, float
         LCM_TRY(gemm_pending(s, "den.initial_proj", s->act_lat, D, m->init_proj, nullptr, B, &pend, st));
         pend.init = 1;
         pend.dup = 1;
+        // one latent per call and no state bag: it sits at position 0 of the learned positions (bias + row 0, see set_schedule)
+        if (m->den_pos_table) pend.bias = s->init_bias_pos;
         for (int l = 0; l < L; ++l) {
             const DenLayer& Ly = m->den[l];
             const float* mod = mod_step + (size_t)l * 9 * dm;
@@ -1241,6 +1277,11 @@ int lcmhip_denoise_positions(lcmhip_session* s, const float* noisy, const int32_
             // The residual stream is updated by the projections' own epilogues (x += gate[row's step] * (h W^T + b)):
             // with many rows no K split is needed, so nothing has to wait in a slab for the next norm kernel.
             LCM_TRY(gemm(s, "pos.initial_proj", s->act_in, D, m->init_proj, nullptr, nullptr, s->xres, dm, R, LCMHIP_EPI_STORE_F32, st));
+            if (m->den_pos_table) {   // position j of a document gets row j of the learned positions
+                hipLaunchKernelGGL(k_row_positions, dim3((R + 255) / 256), dim3(256), 0, st, s->self_rows, R, sc, j0);
+                LCM_HIP_CHECK(hipGetLastError());
+                LCM_TRY(launch_add_pos(s->xres, m->den_pos_table, s->self_rows, R, dm, d.dtype, st));
+            }
             for (int l = 0; l < L; ++l) {
                 const DenLayer& Ly = m->den[l];
                 const float* mod = s->mod_table + (size_t)l * 9 * dm;   // step 0; rows add their own step offset

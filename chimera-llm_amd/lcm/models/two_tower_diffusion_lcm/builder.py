@@ -163,6 +163,8 @@ def parameter_spec(config: TwoTowerDiffusionLCModelConfig,
         ("denoiser.initial_proj.fc.weight", (d, D), "matrix"), ("denoiser.initial_proj.fc.bias", (d,), "zeros"),
         ("denoiser.final_proj.fc.weight", (D, d), "matrix"), ("denoiser.final_proj.fc.bias", (D,), "zeros"),
     ]
+    if config.denoiser.pos_embedding_style == "learned":       # lcm/nn/transformer/factory.py:187-198
+        spec.append(("denoiser.pos_encoder.weight", (config.max_seq_len, d), "pos"))
     stack("denoiser", config.denoiser, denoiser=True)
     return spec
 

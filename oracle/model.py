@@ -243,6 +243,8 @@ class OracleTwoTower:
         key_lens = None if ctx_lens is None else ctx_lens + 1                        # :201-206
         x = linear(latents, sd, "denoiser.initial_proj.fc")                          # :209
         S = x.shape[1]
+        if tc.pos == "learned":                                                      # :211-212, no state bag: from 0
+            x = x + sd["denoiser.pos_encoder.weight"][:S]
         self_mask = torch.eye(S).log()                                               # attention_masks.py:110-113
         for i in range(tc.num_layers):
             p = f"denoiser.layers.{i}"

@@ -102,6 +102,8 @@ def state_dict_spec(cfg: ArchConfig):
     yield "denoiser.initial_proj.fc.bias", (d,), "b"
     yield "denoiser.final_proj.fc.weight", (D, d), "w"
     yield "denoiser.final_proj.fc.bias", (D,), "b"
+    if cfg.denoiser.pos == "learned":         # lcm/nn/transformer/factory.py:187-198 through denoisers/factory.py:143
+        yield "denoiser.pos_encoder.weight", (cfg.max_seq_len, d), "pos"
     yield from _tower_shapes("denoiser", d, cfg.denoiser, cross=True, modulator=True)
 
 

@@ -154,6 +154,59 @@ def test_qk_layernorm(ctx_norm, den_norm, dtype):
         assert cos >= BF16_COS, (worst, cos)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_denoiser_learned_positions(dtype):
+    """`pos_embedding_style="learned"` on the denoiser (lcm/nn/denoisers/factory.py:143, lcm_denoiser.py:211-212): in
+    the sampling loop the single latent sits at position 0 of the table; in the all-positions forward position j gets
+    row j.  Both against the oracle."""
+    from lcm.datasets.batch import EmbeddingsBatch
+    from lcm.models.two_tower_diffusion_lcm import create_two_tower_diffusion_lcm_model
+    from oracle.weights import synthetic_noise, synthetic_prompts
+    cfg = O.get_arch(ARCH)
+    cfg.denoiser.pos = "learned"
+    sd = O.init_state_dict(cfg, seed=8, mod_gain=4.0, qk_gain=1.5)
+    assert sd["denoiser.pos_encoder.weight"].shape == (cfg.max_seq_len, cfg.model_dim)
+    norm = {"center": sd["sonar_normalizer.center"], "scale": sd["sonar_normalizer.scale"]}
+    x, nz = synthetic_prompts(norm, 3, 4, seed=29), synthetic_noise(6, 3, seed=30)
+    opts = dict(DEFAULT_OPTS, inference_timesteps=10)
+    if dtype == torch.bfloat16:
+        sd = {k: O.r16(v) for k, v in sd.items()}
+        x = O.r16(x)
+    ref = run_oracle(cfg, sd, x, nz, 2, opts)
+    mc = mini_config()
+    mc.denoiser.pos_embedding_style = "learned"
+    model = create_two_tower_diffusion_lcm_model(mc, device="cuda:0", dtype=dtype)
+    assert set(model.state_dict()) == set(sd)
+    model.load_state_dict(sd)
+    out = _hip_generate(model, x, nz, 2, opts)
+    worst, cos = compare(out.hypotheses, ref, sd, start=4)
+    if dtype == torch.float32:
+        assert worst <= FP32_MAX_ABS and cos >= FP32_COS, (worst, cos)
+        without = dict(sd)
+        without["denoiser.pos_encoder.weight"] = torch.zeros_like(sd["denoiser.pos_encoder.weight"])
+        w_plain, _ = compare(out.hypotheses, run_oracle(cfg, without, x, nz, 2, opts), sd, start=4)
+        assert w_plain > 10 * FP32_MAX_ABS, w_plain          # the table matters on this problem
+    else:
+        assert cos >= BF16_COS, (worst, cos)
+    # all positions at once: 3 documents x 6 positions, every position its own timestep
+    g = torch.Generator().manual_seed(31)
+    T = 6
+    xs = synthetic_prompts(norm, 3, T, seed=32)
+    x_norm = (xs - norm["center"]) / norm["scale"]
+    if dtype == torch.bfloat16:
+        x_norm = O.r16(x_norm)
+    noisy = torch.randn(3, T, 1024, generator=g)
+    ts = torch.randint(0, cfg.scheduler.num_train_steps, (3, T), generator=g)
+    ref_f = O.OracleTwoTower(cfg, sd).forward(x_norm, noisy, ts)
+    out_f = model.forward(EmbeddingsBatch(x_norm.cuda().to(dtype), None),
+                          EmbeddingsBatch(noisy.cuda(), None, diffusion_timesteps=ts.cuda())).seqs.float().cpu()
+    cos_f = float(torch.nn.functional.cosine_similarity(out_f, ref_f, dim=-1).min())
+    if dtype == torch.float32:
+        assert float((out_f - ref_f).abs().max()) <= FP32_MAX_ABS and cos_f >= FP32_COS, (float((out_f - ref_f).abs().max()), cos_f)
+    else:
+        assert cos_f >= BF16_COS, cos_f
+
+
 def test_clipping_normalizer(tmp_path):
     """A model whose `sonar_normalizer_name` points to a card of the `clipping` arch clamps in normalize (after
     centring / scaling) and in denormalize (before scaling back), inside the fused session kernels too."""
