@@ -45,15 +45,16 @@ __device__ __forceinline__ int big_select_matrix(GemmArgs& p, int bx, int tiles_
 // Residual values of one 32-row round of a wave's output tile, in the lane order in which big_epilogue stores it
 // (RESID only): requested ahead of the round -- round 0 by the kernel itself before the tile is staged (requesting
 // it earlier, with the DMA of the last K tile, measured the same: the read-modify-write is bound by its bytes).
-template <int EPI, bool DUAL>
+// NC: output columns of a wave (64, or 32 for the SwiGLU pairing and for the 32-weight-row wave tile).
+template <int EPI, int NC>
 __host__ __device__ constexpr int big_resid_rounds() {
-    return EPI == LCMHIP_EPI_RESID ? 32 / (64 / ((DUAL ? 32 : 64) / 4)) : 1;
+    return EPI == LCMHIP_EPI_RESID ? 32 / (64 / (NC / 4)) : 1;
 }
-template <int EPI, bool DUAL>
+template <int EPI, int NC>
 __device__ __forceinline__ void big_load_resid(const GemmArgs& p, int m_wave0, int n_wave0, int half, int lane,
-                                               float4 (&o)[big_resid_rounds<EPI, DUAL>()]) {
+                                               float4 (&o)[big_resid_rounds<EPI, NC>()]) {
     if constexpr (EPI == LCMHIP_EPI_RESID) {
-        constexpr int NC = DUAL ? 32 : 64, LPR = NC / 4, RPP = 64 / LPR;
+        constexpr int LPR = NC / 4, RPP = 64 / LPR;
         const int n = n_wave0 + (lane % LPR) * 4;
 #pragma unroll
         for (int ps = 0; ps < 32 / RPP; ++ps) {
@@ -69,12 +70,16 @@ __device__ __forceinline__ void big_load_resid(const GemmArgs& p, int m_wave0, i
 // from there touches 16 rows x 32..64 bytes per instruction.  Each wave instead passes its (16 TM) x 64 tile through
 // its own piece of the (now idle) staging memory, 32 rows at a time, and stores row-contiguous 128..256-byte segments;
 // bias and activations are applied on the way in, the residual update (read-modify-write) and row maps on the way out.
-template <typename T, int EPI, int TM>
-__device__ __forceinline__ void big_epilogue(const GemmArgs& p, const f32x4 (&acc)[4][TM], char* smem, int wid,
+template <int EPI, int TNW>
+__host__ __device__ constexpr int big_wave_cols() { return 16 * (EPI == LCMHIP_EPI_SWIGLU ? TNW / 2 : TNW); }
+
+// TNW: weight-row tiles of the wave (4, or 2 for the 256 x 128 tile); TM: its activation-row tiles.
+template <typename T, int EPI, int TM, int TNW = 4>
+__device__ __forceinline__ void big_epilogue(const GemmArgs& p, const f32x4 (&acc)[TNW][TM], char* smem, int wid,
                                              int m_wave0, int n_wave0, int split, int lane,
-                                             float4 (&res_cur)[big_resid_rounds<EPI, EPI == LCMHIP_EPI_SWIGLU>()]) {
+                                             float4 (&res_cur)[big_resid_rounds<EPI, big_wave_cols<EPI, TNW>()>()]) {
     constexpr bool DUAL = (EPI == LCMHIP_EPI_SWIGLU);
-    constexpr int TNO = DUAL ? 2 : 4;            // output column tiles of the wave
+    constexpr int TNO = DUAL ? TNW / 2 : TNW;    // output column tiles of the wave
     constexpr int NC = 16 * TNO;                 // output columns of the wave
     constexpr int LROW = NC + 4;                 // padded row (floats): 16 rows x one 16-byte piece hit 16 bank groups
     constexpr bool F32OUT = (EPI == EPI_PARTIAL || EPI == LCMHIP_EPI_STORE_F32 || EPI == LCMHIP_EPI_RESID || sizeof(T) == 4);
@@ -93,9 +98,9 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& p, const f32x4 (&ac
         }
     // RESID: the residual values of a 32-row round are requested one round ahead (round 0 by the caller, see
     // big_resid_rounds / big_load_resid), so that the read-modify-write does not wait for a memory round trip per round
-    constexpr int RPASS = big_resid_rounds<EPI, DUAL>();
+    constexpr int RPASS = big_resid_rounds<EPI, NC>();
     float4 res_next[RPASS];
-    auto load_resid = [&](int half, float4 (&o)[RPASS]) { big_load_resid<EPI, DUAL>(p, m_wave0, n_wave0, half, lane, o); };
+    auto load_resid = [&](int half, float4 (&o)[RPASS]) { big_load_resid<EPI, NC>(p, m_wave0, n_wave0, half, lane, o); };
 #pragma unroll
     for (int half = 0; half < TM / 2; ++half) {
         __syncthreads();   // every wave is done with the staging buffers / with the previous round's tile
@@ -111,7 +116,7 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& p, const f32x4 (&ac
                     if constexpr (EPI == LCMHIP_EPI_RELU) v[r] = fmaxf(v[r], 0.f);
                     if constexpr (DUAL) {
                         const float g = v[r];
-                        v[r] = (acc[tn + 2][tm][r] + bv2[tn][r]) * (g / (1.f + __expf(-g)));
+                        v[r] = (acc[tn + TNW / 2][tm][r] + bv2[tn][r]) * (g / (1.f + __expf(-g)));
                     }
                 }
                 *reinterpret_cast<float4*>(tile + (16 * t + frow) * LROW + 16 * tn + quad) = make_float4(v[0], v[1], v[2], v[3]);
@@ -282,8 +287,8 @@ __global__ __launch_bounds__(128 * WMV) void k_gemm_big(GemmArgs p) {
     }
 
     static_assert(2 * STAGE >= NWAVES * 32 * 68 * 4, "the epilogue tiles must fit the staging buffers");
-    float4 res0[big_resid_rounds<EPI, DUAL>()];
-    big_load_resid<EPI, DUAL>(p, m_wave0, n_wave0, 0, lane, res0);
+    float4 res0[big_resid_rounds<EPI, big_wave_cols<EPI, 4>()>()];
+    big_load_resid<EPI, big_wave_cols<EPI, 4>()>(p, m_wave0, n_wave0, 0, lane, res0);
     big_epilogue<bf16_t, EPI, 4>(p, acc, smem, wid, m_wave0, n_wave0, blockIdx.y, lane, res0);
 }
 
@@ -313,9 +318,14 @@ __global__ __launch_bounds__(128 * WMV) void k_gemm_big(GemmArgs p) {
 constexpr int kHT = 128 * kRowB;          // one half-tile: 128 rows x 128 bytes
 constexpr int kBig256Lds = 2 * 4 * kHT;   // 128 KB
 
-template <int EPI>
+// WT = weight-row tiles per wave: 4 (256 weight rows per tile, the description above) or 2 (a 256 x 128 tile for products
+// with too few 256 x 256 tiles: wave tile 128 x 32, one weight half-tile per K tile, 8 matrix-core instructions per
+// phase, the same barriers and hazards; linear epilogues only).
+template <int EPI, int WT>
 __global__ __launch_bounds__(512) void k_gemm_big256(GemmArgs p) {
     constexpr bool DUAL = (EPI == LCMHIP_EPI_SWIGLU);
+    static_assert(WT == 4 || (WT == 2 && !DUAL), "the 256 x 128 tile has no SwiGLU pairing");
+    constexpr int BNW = 64 * WT;              // weight rows of the tile
     extern __shared__ __attribute__((aligned(1024))) char smem256[];
     char* const smem = smem256;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -330,7 +340,7 @@ __global__ __launch_bounds__(512) void k_gemm_big256(GemmArgs p) {
         const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
         const int band = L / (2 * nx), rem = L - band * 2 * nx;
         const int rows = min(2, ny - 2 * band);
-        bx = big_select_matrix(p, rem / rows, p.N / 256);
+        bx = big_select_matrix(p, rem / rows, p.N / BNW);
         by = 2 * band + rem % rows;
     }
     const int m0 = by * 256;
@@ -360,7 +370,7 @@ __global__ __launch_bounds__(512) void k_gemm_big256(GemmArgs p) {
                 offW[h][j] = (uint32_t)(bx * 128 + wcol * 32 + (rr & 31)) * kbytes + piece_off;
                 w2[h][j] = rr >= 32;
             } else {
-                offW[h][j] = (uint32_t)(bx * 256 + t) * kbytes + piece_off;
+                offW[h][j] = (uint32_t)(bx * BNW + t) * kbytes + piece_off;   // WT == 2: only half 0 is ever staged
             }
         }
     const char* const Ab = reinterpret_cast<const char*>(p.A);
@@ -383,9 +393,9 @@ __global__ __launch_bounds__(512) void k_gemm_big256(GemmArgs p) {
         }
     };
 
-    f32x4 acc[4][8];
+    f32x4 acc[WT][8];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < WT; ++a)
 #pragma unroll
         for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -393,13 +403,20 @@ __global__ __launch_bounds__(512) void k_gemm_big256(GemmArgs p) {
     const int frow = lane & 15;
     const int fsw = (frow >> 1) & 7;
     const int x_off = wr * kHT + frow * kRowB;                               // + 16 tm rows
-    const int w_off = (2 + (wc >> 1)) * kHT + ((wc & 1) * 64 + frow) * kRowB;   // + 16 tn rows
+    const int w_off = WT == 4 ? (2 + (wc >> 1)) * kHT + ((wc & 1) * 64 + frow) * kRowB   // + 16 tn rows
+                              : 2 * kHT + (wc * 32 + frow) * kRowB;
     const int slot0 = (((lane >> 4)) ^ fsw) * 16, slot1 = ((4 + (lane >> 4)) ^ fsw) * 16;
 
     // prologue: K tile 0 whole; of K tile 1 the weight halves and activation half 0 (nk >= 4: K is a multiple of 256)
-    stage_w(0, 0, 0); stage_w(1, 0, 0); stage_x(0, 0, 0); stage_x(1, 0, 0);
-    stage_w(0, 1, 1); stage_w(1, 1, 1); stage_x(0, 1, 1);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if constexpr (WT == 4) {
+        stage_w(0, 0, 0); stage_w(1, 0, 0); stage_x(0, 0, 0); stage_x(1, 0, 0);
+        stage_w(0, 1, 1); stage_w(1, 1, 1); stage_x(0, 1, 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        stage_w(0, 0, 0); stage_x(0, 0, 0); stage_x(1, 0, 0);
+        stage_w(0, 1, 1); stage_x(0, 1, 1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
 
     // fragments: w[ks][tn] = the wave's 64 weight rows; x?[ks][b] = activation row tiles 2 i + b of phase i
@@ -420,10 +437,16 @@ __global__ __launch_bounds__(512) void k_gemm_big256(GemmArgs p) {
             _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                  \
                 acc[TN0 + a][2 * (I) + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ks][TN0 + a], XF[ks][b], acc[TN0 + a][2 * (I) + b], 0, 0, 0);
 
-    bf16x8 w[2][4], xe[2][2], xo[2][2];
+    // 4 products of one k-step: weight tiles 0, 1 x the phase's two activation tiles (the 256 x 128 tile)
+#define LCM_MMA4(XF, I, KS)                                                                                \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                          \
+        _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                      \
+            acc[a][2 * (I) + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[KS][a], XF[KS][b], acc[a][2 * (I) + b], 0, 0, 0);
+
+    bf16x8 w[2][WT], xe[2][2], xo[2][2];
     LCM_RD_X2(xe, smem, 0)
     LCM_RD_W2(smem, 0)
-    LCM_RD_W2(smem, 2)
+    if constexpr (WT == 4) LCM_RD_W2(smem, 2)
     // one K tile; MORE1 / MORE2: K tiles kt + 1 / kt + 2 exist (compile-time: the loop body has no branches).
     // hipcc waits for EVERY outstanding LDS read whenever a product needs one, so each phase first issues the half
     // of its products whose operands were read a phase ago, and only then the reads for the next phase.
@@ -433,69 +456,132 @@ __global__ __launch_bounds__(512) void k_gemm_big256(GemmArgs p) {
         const int buf = kt & 1;
         const char* base = smem + buf * (4 * kHT);
         const char* nbase = smem + (buf ^ 1) * (4 * kHT);
-        // ---- phase 0
-        __builtin_amdgcn_s_setprio(1);
-        LCM_MMA8(0, xe, 0)
-        __builtin_amdgcn_s_setprio(0);
-        LCM_PIN();
-        LCM_RD_X2(xo, base, 1)
-        if constexpr (more1) stage_x(1, kt + 1, buf ^ 1);
-        LCM_PIN();
-        __builtin_amdgcn_s_setprio(1);
-        LCM_MMA8(2, xe, 0)
-        __builtin_amdgcn_s_setprio(0);
-        // ---- phase 1: every wave has consumed its weight fragments of this K tile -> barrier A frees the weight halves
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_setprio(1);
-        LCM_MMA8(0, xo, 1)
-        __builtin_amdgcn_s_setprio(0);
-        LCM_PIN();
-        LCM_RD_X2(xe, base, 2)
-        if constexpr (more2) stage_w(0, kt + 2, buf);
-        LCM_PIN();
-        __builtin_amdgcn_s_setprio(1);
-        LCM_MMA8(2, xo, 1)
-        __builtin_amdgcn_s_setprio(0);
-        // ---- phase 2
-        __builtin_amdgcn_s_setprio(1);
-        LCM_MMA8(0, xe, 2)
-        __builtin_amdgcn_s_setprio(0);
-        LCM_PIN();
-        LCM_RD_X2(xo, base, 3)
-        if constexpr (more2) stage_w(1, kt + 2, buf);
-        LCM_PIN();
-        __builtin_amdgcn_s_setprio(1);
-        LCM_MMA8(2, xe, 2)
-        __builtin_amdgcn_s_setprio(0);
-        // ---- phase 3: K tile kt + 1 has landed (at most the two weight half-tiles of kt + 2 pending), all reads of
-        // this buffer's activation halves are complete -> barrier B; then the next tile's fragments: weight tiles
-        // 2-3 in place behind their last products, weight tiles 0-1 into spare registers
-        if constexpr (more2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if constexpr (more2) stage_x(0, kt + 2, buf);
-        __builtin_amdgcn_s_setprio(1);
-        LCM_MMA8(2, xo, 3)
-        __builtin_amdgcn_s_setprio(0);
-        LCM_PIN();
-        bf16x8 wn[2][2];
-        if constexpr (more1) {
-            LCM_RD_X2(xe, nbase, 0)
-            LCM_RD_W2(nbase, 2)
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                wn[0][a] = *reinterpret_cast<const bf16x8*>(nbase + w_off + a * 16 * kRowB + slot0);
-                wn[1][a] = *reinterpret_cast<const bf16x8*>(nbase + w_off + a * 16 * kRowB + slot1);
+        if constexpr (WT == 4) {
+            // ---- phase 0
+            __builtin_amdgcn_s_setprio(1);
+            LCM_MMA8(0, xe, 0)
+            __builtin_amdgcn_s_setprio(0);
+            LCM_PIN();
+            LCM_RD_X2(xo, base, 1)
+            if constexpr (more1) stage_x(1, kt + 1, buf ^ 1);
+            LCM_PIN();
+            __builtin_amdgcn_s_setprio(1);
+            LCM_MMA8(2, xe, 0)
+            __builtin_amdgcn_s_setprio(0);
+            // ---- phase 1: every wave has consumed its weight fragments of this K tile -> barrier A frees the weight halves
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+            LCM_MMA8(0, xo, 1)
+            __builtin_amdgcn_s_setprio(0);
+            LCM_PIN();
+            LCM_RD_X2(xe, base, 2)
+            if constexpr (more2) stage_w(0, kt + 2, buf);
+            LCM_PIN();
+            __builtin_amdgcn_s_setprio(1);
+            LCM_MMA8(2, xo, 1)
+            __builtin_amdgcn_s_setprio(0);
+            // ---- phase 2
+            __builtin_amdgcn_s_setprio(1);
+            LCM_MMA8(0, xe, 2)
+            __builtin_amdgcn_s_setprio(0);
+            LCM_PIN();
+            LCM_RD_X2(xo, base, 3)
+            if constexpr (more2) stage_w(1, kt + 2, buf);
+            LCM_PIN();
+            __builtin_amdgcn_s_setprio(1);
+            LCM_MMA8(2, xe, 2)
+            __builtin_amdgcn_s_setprio(0);
+            // ---- phase 3: K tile kt + 1 has landed (at most the two weight half-tiles of kt + 2 pending), all reads of
+            // this buffer's activation halves are complete -> barrier B; then the next tile's fragments: weight tiles
+            // 2-3 in place behind their last products, weight tiles 0-1 into spare registers
+            if constexpr (more2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if constexpr (more2) stage_x(0, kt + 2, buf);
+            __builtin_amdgcn_s_setprio(1);
+            LCM_MMA8(2, xo, 3)
+            __builtin_amdgcn_s_setprio(0);
+            LCM_PIN();
+            bf16x8 wn[2][2];
+            if constexpr (more1) {
+                LCM_RD_X2(xe, nbase, 0)
+                LCM_RD_W2(nbase, 2)
+    #pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    wn[0][a] = *reinterpret_cast<const bf16x8*>(nbase + w_off + a * 16 * kRowB + slot0);
+                    wn[1][a] = *reinterpret_cast<const bf16x8*>(nbase + w_off + a * 16 * kRowB + slot1);
+                }
             }
-        }
-        LCM_PIN();
-        __builtin_amdgcn_s_setprio(1);
-        LCM_MMA8(0, xo, 3)
-        __builtin_amdgcn_s_setprio(0);
-        if constexpr (more1) {
+            LCM_PIN();
+            __builtin_amdgcn_s_setprio(1);
+            LCM_MMA8(0, xo, 3)
+            __builtin_amdgcn_s_setprio(0);
+            if constexpr (more1) {
+    #pragma unroll
+                for (int a = 0; a < 2; ++a) { w[0][a] = wn[0][a]; w[1][a] = wn[1][a]; }
+            }
+        } else {
+            // ---- the 256 x 128 tile: the same four phases with one weight half-tile and 2 x 4 products per phase
+            __builtin_amdgcn_s_setprio(1);
+            LCM_MMA4(xe, 0, 0)
+            __builtin_amdgcn_s_setprio(0);
+            LCM_PIN();
+            LCM_RD_X2(xo, base, 1)
+            if constexpr (more1) stage_x(1, kt + 1, buf ^ 1);
+            LCM_PIN();
+            __builtin_amdgcn_s_setprio(1);
+            LCM_MMA4(xe, 0, 1)
+            __builtin_amdgcn_s_setprio(0);
+            // ---- phase 1: barrier A frees the weight half
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+            LCM_MMA4(xo, 1, 0)
+            __builtin_amdgcn_s_setprio(0);
+            LCM_PIN();
+            LCM_RD_X2(xe, base, 2)
+            if constexpr (more2) stage_w(0, kt + 2, buf);
+            LCM_PIN();
+            __builtin_amdgcn_s_setprio(1);
+            LCM_MMA4(xo, 1, 1)
+            __builtin_amdgcn_s_setprio(0);
+            // ---- phase 2
+            __builtin_amdgcn_s_setprio(1);
+            LCM_MMA4(xe, 2, 0)
+            __builtin_amdgcn_s_setprio(0);
+            LCM_PIN();
+            LCM_RD_X2(xo, base, 3)
+            LCM_PIN();
+            __builtin_amdgcn_s_setprio(1);
+            LCM_MMA4(xe, 2, 1)
+            __builtin_amdgcn_s_setprio(0);
+            // ---- phase 3: K tile kt + 1 has landed (at most the weight half-tile of kt + 2 pending) -> barrier B
+            if constexpr (more2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if constexpr (more2) stage_x(0, kt + 2, buf);   // (both activation halves here, a phase earlier: 2-4 % slower)
+            __builtin_amdgcn_s_setprio(1);
+            LCM_MMA4(xo, 3, 0)
+            __builtin_amdgcn_s_setprio(0);
+            LCM_PIN();
+            bf16x8 wn[2][2];
+            if constexpr (more1) {
+                LCM_RD_X2(xe, nbase, 0)
 #pragma unroll
-            for (int a = 0; a < 2; ++a) { w[0][a] = wn[0][a]; w[1][a] = wn[1][a]; }
+                for (int a = 0; a < 2; ++a) {
+                    wn[0][a] = *reinterpret_cast<const bf16x8*>(nbase + w_off + a * 16 * kRowB + slot0);
+                    wn[1][a] = *reinterpret_cast<const bf16x8*>(nbase + w_off + a * 16 * kRowB + slot1);
+                }
+            }
+            LCM_PIN();
+            __builtin_amdgcn_s_setprio(1);
+            LCM_MMA4(xo, 3, 1)
+            __builtin_amdgcn_s_setprio(0);
+            if constexpr (more1) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) { w[0][a] = wn[0][a]; w[1][a] = wn[1][a]; }
+            }
         }
     };
     using yes = std::true_type;
@@ -507,10 +593,190 @@ __global__ __launch_bounds__(512) void k_gemm_big256(GemmArgs p) {
 #undef LCM_RD_W2
 #undef LCM_RD_X2
 #undef LCM_MMA8
+#undef LCM_MMA4
 
-    float4 res0[big_resid_rounds<EPI, DUAL>()];
-    big_load_resid<EPI, DUAL>(p, m0 + wr * 128, DUAL ? bx * 128 + wc * 32 : bx * 256 + wc * 64, 0, lane, res0);
-    big_epilogue<bf16_t, EPI, 8>(p, acc, smem, wid, m0 + wr * 128, DUAL ? bx * 128 + wc * 32 : bx * 256 + wc * 64, 0, lane, res0);
+    constexpr int NC = big_wave_cols<EPI, WT>();
+    const int n_wave0 = DUAL ? bx * 128 + wc * 32 : bx * BNW + wc * 16 * WT;
+    float4 res0[big_resid_rounds<EPI, NC>()];
+    big_load_resid<EPI, NC>(p, m0 + wr * 128, n_wave0, 0, lane, res0);
+    big_epilogue<bf16_t, EPI, 8, WT>(p, acc, smem, wid, m0 + wr * 128, n_wave0, 0, lane, res0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 256 (activation rows) x 128 (weight rows) tile, 8 waves as 4 (activation rows) x 2 (weight rows): a wave owns 64 x 64
+// outputs = 4 x 4 accumulator tiles, so a K tile costs it 8 + 8 fragment reads for 32 products (the 128 x 32 wave tile
+// of k_gemm_big256<EPI, 2> needs 16 + 4).  Staging, swizzle, buffers, barriers and hazards are those of k_gemm_big256:
+// two K tiles of [activation half 0][activation half 1][weight half] in LDS, four phases of 8 products (activation tile
+// i of the wave x its 4 weight tiles x both k-steps), barrier A before phase 1 frees the weight half, the counted wait
+// + barrier B in phase 3 publish K tile kt + 1 and free the activation halves.  The weight fragments of tile kt + 1
+// are read in phase 3 behind barrier B together with its first activation tile.
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512) void k_gemm_big256x128(GemmArgs p) {
+    static_assert(EPI != LCMHIP_EPI_SWIGLU, "linear epilogues only");
+    extern __shared__ __attribute__((aligned(1024))) char smem256[];
+    char* const smem = smem256;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    int bx, by;
+    {
+        const int nx = p.tiles_x, ny = p.tiles_y, T = nx * ny;
+        const int id = blockIdx.x, xcd = id & 7, q = T >> 3, r = T & 7;
+        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+        const int band = L / (2 * nx), rem = L - band * 2 * nx;
+        const int rows = min(2, ny - 2 * band);
+        bx = big_select_matrix(p, rem / rows, p.N / 128);
+        by = 2 * band + rem % rows;
+    }
+    const int m0 = by * 256;
+    const uint32_t kbytes = (uint32_t)p.K * 2;
+    const int nk = p.K / 64;
+
+    const int srow = lane >> 3;
+    const uint32_t piece_off = (uint32_t)(((lane & 7) ^ ((4 * (wid & 1) + (srow >> 1)) & 7)) * 16);
+    uint32_t offX[2][2], offW[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = (8 * j + wid) * 8 + srow;      // row inside a half-tile
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int m = m0 + 128 * h + r;
+            m = m < p.M ? m : p.M - 1;               // rows past the end repeat the last row; never stored
+            offX[h][j] = (uint32_t)m * (uint32_t)p.lda * 2u + piece_off;
+        }
+        offW[j] = (uint32_t)(bx * 128 + r) * kbytes + piece_off;
+    }
+    const char* const Ab = reinterpret_cast<const char*>(p.A);
+    const char* const Wb = reinterpret_cast<const char*>(p.W);
+    auto stage_x = [&](int h, int kt, int buf) {
+        char* dst = smem + buf * (4 * kHT) + h * kHT + wid * 1024;
+        const uint32_t koff = (uint32_t)kt * kRowB;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)(Ab + offX[h][j] + koff), (lptr_t)(dst + j * 8192), 16, 0, 0);
+    };
+    auto stage_w = [&](int kt, int buf) {
+        char* dst = smem + buf * (4 * kHT) + 2 * kHT + wid * 1024;
+        const uint32_t koff = (uint32_t)kt * kRowB;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)(Wb + offW[j] + koff), (lptr_t)(dst + j * 8192), 16, 0, 0);
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15;
+    const int fsw = (frow >> 1) & 7;
+    const int x_off = (wr >> 1) * kHT + ((wr & 1) * 64 + frow) * kRowB;     // + 16 tm rows
+    const int w_off = 2 * kHT + (wc * 64 + frow) * kRowB;                   // + 16 tn rows
+    const int slot0 = (((lane >> 4)) ^ fsw) * 16, slot1 = ((4 + (lane >> 4)) ^ fsw) * 16;
+
+    // prologue: K tile 0 whole; of K tile 1 the weight half and activation half 0 (nk >= 2)
+    stage_w(0, 0); stage_x(0, 0, 0); stage_x(1, 0, 0);
+    stage_w(1, 1); stage_x(0, 1, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+#define LCM_RD_X1(DST, BASE, TM)                                                                      \
+    {                                                                                                 \
+        DST[0] = *reinterpret_cast<const bf16x8*>((BASE) + x_off + (TM) * 16 * kRowB + slot0);        \
+        DST[1] = *reinterpret_cast<const bf16x8*>((BASE) + x_off + (TM) * 16 * kRowB + slot1);        \
+    }
+#define LCM_RD_W4(DST, BASE)                                                                          \
+    _Pragma("unroll") for (int a = 0; a < 4; ++a) {                                                   \
+        DST[0][a] = *reinterpret_cast<const bf16x8*>((BASE) + w_off + a * 16 * kRowB + slot0);        \
+        DST[1][a] = *reinterpret_cast<const bf16x8*>((BASE) + w_off + a * 16 * kRowB + slot1);        \
+    }
+    // 4 products: the wave's 4 weight tiles x activation tile TM, k-step KS
+#define LCM_MMA4W(XF, TM, KS)                                                                         \
+    _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                     \
+        acc[a][TM] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[KS][a], XF[KS], acc[a][TM], 0, 0, 0);
+#define LCM_PIN() __builtin_amdgcn_sched_barrier(0)
+
+    bf16x8 w[2][4], xe[2], xo[2];
+    LCM_RD_X1(xe, smem, 0)
+    LCM_RD_W4(w, smem)
+    auto tile = [&](int kt, auto more1_t, auto more2_t) {
+        constexpr bool more1 = decltype(more1_t)::value, more2 = decltype(more2_t)::value;
+        const int buf = kt & 1;
+        const char* base = smem + buf * (4 * kHT);
+        const char* nbase = smem + (buf ^ 1) * (4 * kHT);
+        // ---- phase 0
+        __builtin_amdgcn_s_setprio(1);
+        LCM_MMA4W(xe, 0, 0)
+        __builtin_amdgcn_s_setprio(0);
+        LCM_PIN();
+        LCM_RD_X1(xo, base, 1)
+        if constexpr (more1) stage_x(1, kt + 1, buf ^ 1);
+        LCM_PIN();
+        __builtin_amdgcn_s_setprio(1);
+        LCM_MMA4W(xe, 0, 1)
+        __builtin_amdgcn_s_setprio(0);
+        // ---- phase 1: every wave has consumed its weight fragments of this K tile -> barrier A frees the weight half
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+        LCM_MMA4W(xo, 1, 0)
+        __builtin_amdgcn_s_setprio(0);
+        LCM_PIN();
+        LCM_RD_X1(xe, base, 2)
+        if constexpr (more2) stage_w(kt + 2, buf);
+        LCM_PIN();
+        __builtin_amdgcn_s_setprio(1);
+        LCM_MMA4W(xo, 1, 1)
+        __builtin_amdgcn_s_setprio(0);
+        // ---- phase 2
+        __builtin_amdgcn_s_setprio(1);
+        LCM_MMA4W(xe, 2, 0)
+        __builtin_amdgcn_s_setprio(0);
+        LCM_PIN();
+        LCM_RD_X1(xo, base, 3)
+        LCM_PIN();
+        __builtin_amdgcn_s_setprio(1);
+        LCM_MMA4W(xe, 2, 1)
+        __builtin_amdgcn_s_setprio(0);
+        // ---- phase 3: K tile kt + 1 has landed (at most the weight half-tile of kt + 2 pending), no LDS read pending
+        if constexpr (more2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if constexpr (more2) stage_x(0, kt + 2, buf);
+        __builtin_amdgcn_s_setprio(1);
+        LCM_MMA4W(xo, 3, 0)
+        __builtin_amdgcn_s_setprio(0);
+        LCM_PIN();
+        bf16x8 wn[2][4];
+        if constexpr (more1) {
+            LCM_RD_X1(xe, nbase, 0)
+            LCM_RD_W4(wn, nbase)
+        }
+        LCM_PIN();
+        __builtin_amdgcn_s_setprio(1);
+        LCM_MMA4W(xo, 3, 1)
+        __builtin_amdgcn_s_setprio(0);
+        if constexpr (more1) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { w[0][a] = wn[0][a]; w[1][a] = wn[1][a]; }
+        }
+    };
+    using yes = std::true_type;
+    using no = std::false_type;
+    for (int kt = 0; kt < nk - 2; ++kt) tile(kt, yes{}, yes{});
+    tile(nk - 2, yes{}, no{});
+    tile(nk - 1, no{}, no{});
+#undef LCM_PIN
+#undef LCM_RD_X1
+#undef LCM_RD_W4
+#undef LCM_MMA4W
+
+    constexpr int NC = big_wave_cols<EPI, 4>();
+    const int m_wave0 = m0 + wr * 64, n_wave0 = bx * 128 + wc * 64;
+    float4 res0[big_resid_rounds<EPI, NC>()];
+    big_load_resid<EPI, NC>(p, m_wave0, n_wave0, 0, lane, res0);
+    big_epilogue<bf16_t, EPI, 4>(p, acc, smem, wid, m_wave0, n_wave0, 0, lane, res0);
 }
 
 // K splits for the split-K (slab) form: two workgroups per CU (512; with one per CU a workgroup's four waves have
@@ -570,26 +836,72 @@ static bool big256_applicable(const GemmArgs& a, int epi, int splits, int m_rows
     return ratio10 * waves256 < 10 * waves128;
 }
 
-static int launch_gemm_big256(const GemmArgs& a_in, int epi, int m_rows, hipStream_t st) {
+// The 256 x 128 tile (wave tile 128 x 32) for linear products whose 256 x 256 tiles would leave CUs idle.
+// LCMHIP_BIG256_N128: 0 = never, 1 = when its tiles fill at least 3/4 of one wave of CUs and the 256 x 256 kernel does not
+// apply (default, see the measurements at the routing below), 2 = whenever the shape allows (measurements).
+static bool big256n128_applicable(const GemmArgs& a, int epi, int splits, int m_rows) {
+    const char* e = getenv("LCMHIP_BIG256_N128");   // read per call: the A/B script switches it inside one process
+    const int mode = e ? atoi(e) : 0;
+    if (mode == 0 || splits != 1 || epi == EPI_PARTIAL || epi == LCMHIP_EPI_SWIGLU) return false;
+    if (a.N % 128 != 0 || a.K % 64 != 0 || a.K < 128) return false;
+    const int wrows = a.N * std::max(1, a.stack);
+    if ((size_t)a.M * a.lda * 2 >= (1ull << 31) || (size_t)a.N * a.K * 2 >= (1ull << 31)) return false;
+    const int tiles = (wrows / 128) * ((m_rows + 255) / 256);
+    if (mode >= 2) return true;
+    const int rem = tiles % 256;
+    return tiles >= 192 && (rem == 0 || rem >= 192);
+}
+
+static int launch_gemm_big256(const GemmArgs& a_in, int epi, int m_rows, int wt, hipStream_t st) {
     const int wrows = (epi == LCMHIP_EPI_SWIGLU ? 2 * a_in.N : a_in.N) * std::max(1, a_in.stack);
     GemmArgs a = a_in;
-    a.tiles_x = wrows / 256;
+    a.tiles_x = wrows / (64 * wt);
     a.tiles_y = (m_rows + 255) / 256;
     dim3 grid(a.tiles_x * a.tiles_y), block(512);
-#define LCM_BIG256(E)                                                                                              \
+#define LCM_BIG256(E, W)                                                                                           \
     {                                                                                                              \
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_big256<E>),       \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_big256<E, W>),    \
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, kBig256Lds); \
         LCM_HIP_CHECK(attr);                                                                                       \
-        hipLaunchKernelGGL((k_gemm_big256<E>), grid, block, kBig256Lds, st, a);                                    \
+        hipLaunchKernelGGL((k_gemm_big256<E, W>), grid, block, kBig256Lds, st, a);                                 \
     }
-    switch (epi) {
-        case LCMHIP_EPI_STORE: LCM_BIG256(LCMHIP_EPI_STORE); break;
-        case LCMHIP_EPI_STORE_F32: LCM_BIG256(LCMHIP_EPI_STORE_F32); break;
-        case LCMHIP_EPI_RELU: LCM_BIG256(LCMHIP_EPI_RELU); break;
-        case LCMHIP_EPI_SWIGLU: LCM_BIG256(LCMHIP_EPI_SWIGLU); break;
-        case LCMHIP_EPI_RESID: LCM_BIG256(LCMHIP_EPI_RESID); break;
-        default: return fail(LCMHIP_ERR_INVALID, "gemm: unknown epilogue");
+    if (wt == 4) {
+        switch (epi) {
+            case LCMHIP_EPI_STORE: LCM_BIG256(LCMHIP_EPI_STORE, 4); break;
+            case LCMHIP_EPI_STORE_F32: LCM_BIG256(LCMHIP_EPI_STORE_F32, 4); break;
+            case LCMHIP_EPI_RELU: LCM_BIG256(LCMHIP_EPI_RELU, 4); break;
+            case LCMHIP_EPI_SWIGLU: LCM_BIG256(LCMHIP_EPI_SWIGLU, 4); break;
+            case LCMHIP_EPI_RESID: LCM_BIG256(LCMHIP_EPI_RESID, 4); break;
+            default: return fail(LCMHIP_ERR_INVALID, "gemm: unknown epilogue");
+        }
+    } else {
+        // wave layout of the 256 x 128 tile: 4 x 2 waves of 64 x 64 (default) or, LCMHIP_BIG256_N128_LAYOUT=1, 2 x 4 of 128 x 32
+        static const int layout = [] { const char* e = getenv("LCMHIP_BIG256_N128_LAYOUT"); return e ? atoi(e) : 0; }();
+#define LCM_BIG256X128(E)                                                                                              \
+    {                                                                                                                  \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_big256x128<E>),       \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kBig256Lds);    \
+        LCM_HIP_CHECK(attr);                                                                                           \
+        hipLaunchKernelGGL((k_gemm_big256x128<E>), grid, block, kBig256Lds, st, a);                                    \
+    }
+        if (layout == 1) {
+            switch (epi) {
+                case LCMHIP_EPI_STORE: LCM_BIG256(LCMHIP_EPI_STORE, 2); break;
+                case LCMHIP_EPI_STORE_F32: LCM_BIG256(LCMHIP_EPI_STORE_F32, 2); break;
+                case LCMHIP_EPI_RELU: LCM_BIG256(LCMHIP_EPI_RELU, 2); break;
+                case LCMHIP_EPI_RESID: LCM_BIG256(LCMHIP_EPI_RESID, 2); break;
+                default: return fail(LCMHIP_ERR_INVALID, "gemm: the 256 x 128 tile takes linear epilogues only");
+            }
+        } else {
+            switch (epi) {
+                case LCMHIP_EPI_STORE: LCM_BIG256X128(LCMHIP_EPI_STORE); break;
+                case LCMHIP_EPI_STORE_F32: LCM_BIG256X128(LCMHIP_EPI_STORE_F32); break;
+                case LCMHIP_EPI_RELU: LCM_BIG256X128(LCMHIP_EPI_RELU); break;
+                case LCMHIP_EPI_RESID: LCM_BIG256X128(LCMHIP_EPI_RESID); break;
+                default: return fail(LCMHIP_ERR_INVALID, "gemm: the 256 x 128 tile takes linear epilogues only");
+            }
+        }
+#undef LCM_BIG256X128
     }
 #undef LCM_BIG256
     LCM_HIP_CHECK(hipGetLastError());
@@ -600,7 +912,8 @@ int launch_gemm_big(const GemmArgs& a, int epi, int splits, int m_rows, hipStrea
     if (a.stack > 1)
         LCM_REQUIRE(a.stack <= 3 && splits == 1 && a.N % kBN == 0 && (epi == LCMHIP_EPI_STORE || epi == LCMHIP_EPI_STORE_F32 || epi == LCMHIP_EPI_RELU),
                     "gemm: stacked products take up to 3 matrices, a linear epilogue and no K split");
-    if (big256_applicable(a, epi, splits, m_rows)) return launch_gemm_big256(a, epi, m_rows, st);
+    if (big256_applicable(a, epi, splits, m_rows)) return launch_gemm_big256(a, epi, m_rows, 4, st);
+    if (big256n128_applicable(a, epi, splits, m_rows)) return launch_gemm_big256(a, epi, m_rows, 2, st);
     const int wrows = (epi == LCMHIP_EPI_SWIGLU ? 2 * a.N : a.N) * std::max(1, a.stack);
     // (256 x 128 tiles with 8 waves and one workgroup per CU measured 10-20 % slower than two 128 x 128 workgroups.)
     dim3 grid(wrows / kBN, splits, (m_rows + kBM - 1) / kBM), block(256);

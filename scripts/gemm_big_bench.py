@@ -13,7 +13,8 @@ def bench(M, N, K, epi):
     A = torch.randn(M, K, device=dev).bfloat16()
     W = (torch.randn(N, K, device=dev) * 0.02).bfloat16()
     W2 = (torch.randn(N, K, device=dev) * 0.02).bfloat16() if epi == _hip.EPI_SWIGLU else None
-    out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    f32_out = epi in (_hip.EPI_RESID, _hip.EPI_STORE_F32)
+    out = torch.zeros(M, N, device=dev, dtype=torch.float32 if f32_out else torch.bfloat16)
     def run():
         _hip.check(_hip.lib.lcmhip_gemm(_hip.ptr(A), K, _hip.ptr(W), _hip.ptr(W2), None, None, None, _hip.ptr(out), N,
                                         M, N, K, epi, _hip.BF16, None, 0, st))
@@ -35,9 +36,43 @@ def bench(M, N, K, epi):
         us_t = 1e3 * e0.elapsed_time(e1) / ITERS
     print(f"M={M:5d} N={N:5d} K={K:5d} epi={epi}  {us:8.1f} us  {flops / us / 1e6:7.1f} TFLOP/s   (torch/hipBLASLt linear: {2.0*M*N*K / us_t / 1e6:7.1f})", flush=True)
 
+def ab_n128():
+    """The 256 x 128 tile against the 128 x 128 kernel on the one-tile-per-CU shapes, alternating inside one process."""
+    shapes = [(4096, 2048, 2048, _hip.EPI_STORE), (4096, 2048, 5632, _hip.EPI_STORE), (4096, 2048, 2048, _hip.EPI_RESID),
+              (4096, 2048, 5632, _hip.EPI_RESID), (4096, 6144, 2048, _hip.EPI_STORE), (2048, 2048, 2048, _hip.EPI_STORE)]
+    for M, N, K, epi in shapes:
+        A = torch.randn(M, K, device=dev).bfloat16()
+        W = (torch.randn(N, K, device=dev) * 0.02).bfloat16()
+        out = torch.zeros(M, N, device=dev, dtype=torch.float32 if epi == _hip.EPI_RESID else torch.bfloat16)
+        res = {}
+        for rnd in range(3):
+            for mode in ("0", "2"):
+                os.environ["LCMHIP_BIG256_N128"] = mode
+                def run():
+                    _hip.check(_hip.lib.lcmhip_gemm(_hip.ptr(A), K, _hip.ptr(W), None, None, None, None, _hip.ptr(out), N,
+                                                    M, N, K, epi, _hip.BF16, None, 0, st))
+                for _ in range(3): run()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(50): run()
+                e1.record(); torch.cuda.synchronize()
+                res.setdefault(mode, []).append(1e3 * e0.elapsed_time(e1) / 50)
+        a, b = min(res["0"]), min(res["2"])
+        print(f"M={M} N={N} K={K} epi={epi}: 128x128 kernel {a:7.1f} us, 256x128 tile {b:7.1f} us  ({100 * (a / b - 1):+.1f} %)", flush=True)
+    os.environ.pop("LCMHIP_BIG256_N128", None)
+
+if os.environ.get("GB_AB_N128"):
+    ab_n128()
+    sys.exit(0)
+
 for M in ROWS:
     bench(M, 2048, 2048, _hip.EPI_STORE)
     bench(M, 5632, 2048, _hip.EPI_SWIGLU)
     bench(M, 2048, 5632, _hip.EPI_STORE)
+    if M >= 1024:
+        bench(M, 2048, 2048, _hip.EPI_RESID)
+        bench(M, 2048, 5632, _hip.EPI_RESID)
+        bench(M, 6144, 2048, _hip.EPI_STORE)
 bench(4096, 4096, 4096, _hip.EPI_STORE)
 bench(8192, 8192, 8192, _hip.EPI_STORE)
