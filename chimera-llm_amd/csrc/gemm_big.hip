@@ -675,102 +675,106 @@ __global__ __launch_bounds__(512) void k_gemm_big256x128(GemmArgs p) {
     const int w_off = 2 * kHT + (wc * 64 + frow) * kRowB;                   // + 16 tn rows
     const int slot0 = (((lane >> 4)) ^ fsw) * 16, slot1 = ((4 + (lane >> 4)) ^ fsw) * 16;
 
-    // prologue: K tile 0 whole; of K tile 1 the weight half and activation half 0 (nk >= 2)
+    // prologue: K tile 0 whole; of K tile 1 the weight half and activation half 0 (nk >= 4)
     stage_w(0, 0); stage_x(0, 0, 0); stage_x(1, 0, 0);
     stage_w(1, 1); stage_x(0, 1, 1);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-#define LCM_RD_X1(DST, BASE, TM)                                                                      \
-    {                                                                                                 \
-        DST[0] = *reinterpret_cast<const bf16x8*>((BASE) + x_off + (TM) * 16 * kRowB + slot0);        \
-        DST[1] = *reinterpret_cast<const bf16x8*>((BASE) + x_off + (TM) * 16 * kRowB + slot1);        \
-    }
-#define LCM_RD_W4(DST, BASE)                                                                          \
-    _Pragma("unroll") for (int a = 0; a < 4; ++a) {                                                   \
-        DST[0][a] = *reinterpret_cast<const bf16x8*>((BASE) + w_off + a * 16 * kRowB + slot0);        \
-        DST[1][a] = *reinterpret_cast<const bf16x8*>((BASE) + w_off + a * 16 * kRowB + slot1);        \
-    }
-    // 4 products: the wave's 4 weight tiles x activation tile TM, k-step KS
-#define LCM_MMA4W(XF, TM, KS)                                                                         \
-    _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                     \
-        acc[a][TM] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[KS][a], XF[KS], acc[a][TM], 0, 0, 0);
+    // Fragment reads are issued by hand (ds_read_b128 through inline asm) and retired with COUNTED lgkmcnt waits: the
+    // compiler's own waits drain every pending LDS read before a product, which leaves a read only the few products
+    // issued behind it to land.  Reads retire in order, so "at most n younger reads pending" retires a fragment.  The
+    // compiler does not know that an asm result is still in flight: every wait is followed by a scheduling fence so that
+    // no product moves above it, nothing copies a fragment (the weight fragments of consecutive K tiles alternate
+    // between two register sets instead), and the last tile ends with lgkmcnt(0).
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+    const uint32_t xa[2] = {lds0 + (uint32_t)(x_off + slot0), lds0 + (uint32_t)(x_off + slot1)};
+    const uint32_t wa[2] = {lds0 + (uint32_t)(w_off + slot0), lds0 + (uint32_t)(w_off + slot1)};
+#define LCM_DSR(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "i"(OFF))
+#define LCM_LGKM(N) asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : "memory")
 #define LCM_PIN() __builtin_amdgcn_sched_barrier(0)
+    // activation tile TM of K-tile buffer BUF (compile-time): both k-steps
+#define LCM_RD_X1(DST, BUF, TM)                                      \
+    {                                                                \
+        LCM_DSR(DST[0], xb[BUF][0], (TM) * 16 * kRowB);              \
+        LCM_DSR(DST[1], xb[BUF][1], (TM) * 16 * kRowB);              \
+    }
+    // weight tiles TN0, TN0 + 1 of K-tile buffer BUF: both k-steps
+#define LCM_RD_W2(DST, BUF, TN0)                                             \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a) {                          \
+        LCM_DSR(DST[0][TN0 + a], wb[BUF][0], ((TN0) + a) * 16 * kRowB);      \
+        LCM_DSR(DST[1][TN0 + a], wb[BUF][1], ((TN0) + a) * 16 * kRowB);      \
+    }
+    // 8 products: the wave's 4 weight tiles x activation tile TM x both k-steps
+#define LCM_MMA8W(WF, XF, TM)                                                                                  \
+    __builtin_amdgcn_s_setprio(1);                                                                             \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                           \
+        _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                          \
+            acc[a][TM] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[ks][a], XF[ks], acc[a][TM], 0, 0, 0);      \
+    __builtin_amdgcn_s_setprio(0);
 
-    bf16x8 w[2][4], xe[2], xo[2];
-    LCM_RD_X1(xe, smem, 0)
-    LCM_RD_W4(w, smem)
-    auto tile = [&](int kt, auto more1_t, auto more2_t) {
-        constexpr bool more1 = decltype(more1_t)::value, more2 = decltype(more2_t)::value;
-        const int buf = kt & 1;
-        const char* base = smem + buf * (4 * kHT);
-        const char* nbase = smem + (buf ^ 1) * (4 * kHT);
-        // ---- phase 0
-        __builtin_amdgcn_s_setprio(1);
-        LCM_MMA4W(xe, 0, 0)
-        __builtin_amdgcn_s_setprio(0);
-        LCM_PIN();
-        LCM_RD_X1(xo, base, 1)
-        if constexpr (more1) stage_x(1, kt + 1, buf ^ 1);
-        LCM_PIN();
-        __builtin_amdgcn_s_setprio(1);
-        LCM_MMA4W(xe, 0, 1)
-        __builtin_amdgcn_s_setprio(0);
-        // ---- phase 1: every wave has consumed its weight fragments of this K tile -> barrier A frees the weight half
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_setprio(1);
-        LCM_MMA4W(xo, 1, 0)
-        __builtin_amdgcn_s_setprio(0);
-        LCM_PIN();
-        LCM_RD_X1(xe, base, 2)
-        if constexpr (more2) stage_w(kt + 2, buf);
-        LCM_PIN();
-        __builtin_amdgcn_s_setprio(1);
-        LCM_MMA4W(xo, 1, 1)
-        __builtin_amdgcn_s_setprio(0);
-        // ---- phase 2
-        __builtin_amdgcn_s_setprio(1);
-        LCM_MMA4W(xe, 2, 0)
-        __builtin_amdgcn_s_setprio(0);
-        LCM_PIN();
-        LCM_RD_X1(xo, base, 3)
-        LCM_PIN();
-        __builtin_amdgcn_s_setprio(1);
-        LCM_MMA4W(xe, 2, 1)
-        __builtin_amdgcn_s_setprio(0);
-        // ---- phase 3: K tile kt + 1 has landed (at most the weight half-tile of kt + 2 pending), no LDS read pending
-        if constexpr (more2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if constexpr (more2) stage_x(0, kt + 2, buf);
-        __builtin_amdgcn_s_setprio(1);
-        LCM_MMA4W(xo, 3, 0)
-        __builtin_amdgcn_s_setprio(0);
-        LCM_PIN();
-        bf16x8 wn[2][4];
-        if constexpr (more1) {
-            LCM_RD_X1(xe, nbase, 0)
-            LCM_RD_W4(wn, nbase)
-        }
-        LCM_PIN();
-        __builtin_amdgcn_s_setprio(1);
-        LCM_MMA4W(xo, 3, 1)
-        __builtin_amdgcn_s_setprio(0);
-        if constexpr (more1) {
-#pragma unroll
-            for (int a = 0; a < 4; ++a) { w[0][a] = wn[0][a]; w[1][a] = wn[1][a]; }
-        }
-    };
-    using yes = std::true_type;
-    using no = std::false_type;
-    for (int kt = 0; kt < nk - 2; ++kt) tile(kt, yes{}, yes{});
-    tile(nk - 2, yes{}, no{});
-    tile(nk - 1, no{}, no{});
-#undef LCM_PIN
+    // the two K-tile buffers are 64 KB apart: beyond the 16-bit offset field, so each has its own base registers
+    const uint32_t xb[2][2] = {{xa[0], xa[1]}, {xa[0] + 4u * kHT, xa[1] + 4u * kHT}};
+    const uint32_t wb[2][2] = {{wa[0], wa[1]}, {wa[0] + 4u * kHT, wa[1] + 4u * kHT}};
+
+    bf16x8 wA[2][4], wB[2][4], xe[2], xo[2];
+    LCM_RD_X1(xe, 0, 0)
+    LCM_RD_W2(wA, 0, 0)
+    LCM_RD_W2(wA, 0, 2)
+    // One K tile in buffer BUF; WC = its weight fragments (read during the previous tile), WN = the register set that
+    // receives the next tile's.  LDS reads per phase: 2 / 6 / 6 / 2.
+    //   phase 0: read X1                     | DMA X-half 1 of tile kt+1         | retire X0 (+ all of WC) | products on X0
+    //   phase 1: wait: W(kt+1) landed; barrier A (frees this buffer's weight half, publishes W(kt+1))
+    //            read X2, WN tiles 0-1       | DMA W of tile kt+2 (this buffer)  | retire X1               | products on X1
+    //   phase 2: read X3, WN tiles 2-3                                            | retire X2               | products on X2
+    //   phase 3: wait: X(kt+1) landed, no LDS read pending; barrier B (frees this buffer's activation halves)
+    //            read X0 of tile kt+1        | DMA X-half 0 of tile kt+2                                    | products on X3
+#define LCM_TILE(BUF, KT, WC, WN, MORE1, MORE2)                                                        \
+    {                                                                                                  \
+        LCM_RD_X1(xo, BUF, 1)                                                                          \
+        if (MORE1) stage_x(1, (KT) + 1, (BUF) ^ 1);                                                    \
+        LCM_LGKM(2);                                                                                   \
+        LCM_PIN();                                                                                     \
+        LCM_MMA8W(WC, xe, 0)                                                                           \
+        LCM_PIN();                                                                                     \
+        if (MORE1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                    \
+        __builtin_amdgcn_s_barrier();                                                                  \
+        LCM_RD_X1(xe, BUF, 2)                                                                          \
+        if (MORE1) { LCM_RD_W2(WN, (BUF) ^ 1, 0) }                                                     \
+        if (MORE2) stage_w((KT) + 2, BUF);                                                             \
+        if (MORE1) { LCM_LGKM(6); } else { LCM_LGKM(2); }                                              \
+        LCM_PIN();                                                                                     \
+        LCM_MMA8W(WC, xo, 1)                                                                           \
+        LCM_PIN();                                                                                     \
+        LCM_RD_X1(xo, BUF, 3)                                                                          \
+        if (MORE1) { LCM_RD_W2(WN, (BUF) ^ 1, 2) }                                                     \
+        if (MORE1) { LCM_LGKM(10); } else { LCM_LGKM(2); }                                             \
+        LCM_PIN();                                                                                     \
+        LCM_MMA8W(WC, xe, 2)                                                                           \
+        LCM_PIN();                                                                                     \
+        if (MORE2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                    \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
+        LCM_LGKM(0);                                                                                   \
+        __builtin_amdgcn_s_barrier();                                                                  \
+        if (MORE2) stage_x(0, (KT) + 2, BUF);                                                          \
+        if (MORE1) { LCM_RD_X1(xe, (BUF) ^ 1, 0) }                                                     \
+        LCM_PIN();                                                                                     \
+        LCM_MMA8W(WC, xo, 3)                                                                           \
+        LCM_PIN();                                                                                     \
+    }
+    for (int kt = 0; kt < nk - 2; kt += 2) {
+        LCM_TILE(0, kt, wA, wB, true, true)
+        LCM_TILE(1, kt + 1, wB, wA, true, true)
+    }
+    LCM_TILE(0, nk - 2, wA, wB, true, false)
+    LCM_TILE(1, nk - 1, wB, wA, false, false)
+#undef LCM_TILE
+#undef LCM_MMA8W
+#undef LCM_RD_W2
 #undef LCM_RD_X1
-#undef LCM_RD_W4
-#undef LCM_MMA4W
+#undef LCM_PIN
+#undef LCM_LGKM
+#undef LCM_DSR
 
     constexpr int NC = big_wave_cols<EPI, 4>();
     const int m_wave0 = m0 + wr * 64, n_wave0 = bx * 128 + wc * 64;
