@@ -609,7 +609,12 @@ __global__ __launch_bounds__(512) void k_gemm_big256(GemmArgs p) {
 // two K tiles of [activation half 0][activation half 1][weight half] in LDS, four phases of 8 products (activation tile
 // i of the wave x its 4 weight tiles x both k-steps), barrier A before phase 1 frees the weight half, the counted wait
 // + barrier B in phase 3 publish K tile kt + 1 and free the activation halves.  The weight fragments of tile kt + 1
-// are read in phase 3 behind barrier B together with its first activation tile.
+// are read during phases 1-2 of tile kt (its weight half is published at barrier A by a counted vmcnt), its first
+// activation tile in phase 3 behind barrier B.  Measured on 4096 x 2048 x 2048 / x 5632 against the 128 x 128 kernel
+// (45-46 / 95 us on the slower device class): compiler-issued fragment reads 42.4 / 88.9 us, hand-issued reads with
+// counted waits 40.8-42.3 / 84.6-84.9 us; a ring of three K tiles in LDS with the DMA two tiles ahead 42.1-43.4 /
+// 87.3-87.5 us (slower: the loop is not waiting for memory); the 2 x 4 wave layout (wave tile 128 x 32) equal to this one
+// with compiler-issued reads.
 // ------------------------------------------------------------------------------------------------
 template <int EPI>
 __global__ __launch_bounds__(512) void k_gemm_big256x128(GemmArgs p) {
@@ -847,7 +852,7 @@ static bool big256n128_applicable(const GemmArgs& a, int epi, int splits, int m_
     const char* e = getenv("LCMHIP_BIG256_N128");   // read per call: the A/B script switches it inside one process
     const int mode = e ? atoi(e) : 0;
     if (mode == 0 || splits != 1 || epi == EPI_PARTIAL || epi == LCMHIP_EPI_SWIGLU) return false;
-    if (a.N % 128 != 0 || a.K % 64 != 0 || a.K < 128) return false;
+    if (a.N % 128 != 0 || a.K % 128 != 0 || a.K < 256) return false;   // the K loop runs in pairs of 64-wide tiles
     const int wrows = a.N * std::max(1, a.stack);
     if ((size_t)a.M * a.lda * 2 >= (1ull << 31) || (size_t)a.N * a.K * 2 >= (1ull << 31)) return false;
     const int tiles = (wrows / 128) * ((m_rows + 255) / 256);
