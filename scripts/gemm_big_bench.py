@@ -63,6 +63,9 @@ def ab_n128():
     os.environ.pop("LCMHIP_BIG256_N128", None)
 
 if os.environ.get("GB_AB_N128"):
+    pr = torch.cuda.get_device_properties(0)
+    print(f"device: {pr.name}, {pr.multi_processor_count} CUs, clock {getattr(pr, 'clock_rate', 0) / 1e3:.0f} MHz, "
+          f"memory clock {getattr(pr, 'memory_clock_rate', 0) / 1e3:.0f} MHz, {pr.total_memory / 2**30:.0f} GiB", flush=True)
     ab_n128()
     sys.exit(0)
 
