@@ -885,7 +885,8 @@ static int launch_gemm_big256(const GemmArgs& a_in, int epi, int m_rows, int wt,
         }
     } else {
         // wave layout of the 256 x 128 tile: 4 x 2 waves of 64 x 64 (default) or, LCMHIP_BIG256_N128_LAYOUT=1, 2 x 4 of 128 x 32
-        static const int layout = [] { const char* e = getenv("LCMHIP_BIG256_N128_LAYOUT"); return e ? atoi(e) : 0; }();
+        const char* le = getenv("LCMHIP_BIG256_N128_LAYOUT");   // read per call, like the mode
+        const int layout = le ? atoi(le) : 0;
 #define LCM_BIG256X128(E)                                                                                              \
     {                                                                                                                  \
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_big256x128<E>),       \

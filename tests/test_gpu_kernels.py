@@ -117,6 +117,52 @@ def test_gemm_one_tile_per_cu(hip, M, K):
     _check_epilogues(hip, torch.bfloat16, M, 6400, K, False)
 
 
+@pytest.mark.parametrize("layout", ["0", "1"])
+@pytest.mark.parametrize("M,N,K", [(4096, 2048, 2048), (4000, 2048, 768), (3700, 6144, 256), (513, 1280, 5632)])
+def test_gemm_256x128_tile(hip, monkeypatch, M, N, K, layout):
+    """The 256 x 128 tile kernels (LCMHIP_BIG256_N128=2; layout 0: wave tile 64 x 64 with hand-issued fragment reads and
+    counted waits, layout 1: wave tile 128 x 32) against float64 through every linear epilogue, and bit for bit against
+    the default routing: every output sums its K tiles in the same order in all of these kernels.  Ragged row counts,
+    the shortest K loop the interface allows (4 K tiles), several waves of tiles."""
+    import os
+    dt = torch.bfloat16
+    torch.manual_seed(M + N + K)
+    A = torch.randn(M, K).cuda().to(dt)
+    W = (torch.randn(N, K) / math.sqrt(K)).cuda().to(dt)
+    b = torch.randn(N).cuda().to(dt)
+    gate = torch.randn(N).cuda()
+    res0 = torch.randn(M, N).cuda()
+
+    def run_all():
+        outs = []
+        for epi in (hip.EPI_STORE, hip.EPI_RELU):
+            o = torch.empty(M, N, device="cuda", dtype=dt)
+            _gemm(hip, A, W, None, b, None, None, o, epi)
+            outs.append(o)
+        o32 = torch.empty(M, N, device="cuda")
+        _gemm(hip, A, W, None, None, None, None, o32, hip.EPI_STORE_F32)
+        outs.append(o32)
+        r = res0.clone()
+        _gemm(hip, A, W, None, b, None, gate, r, hip.EPI_RESID)
+        outs.append(r)
+        torch.cuda.synchronize()
+        return outs
+
+    monkeypatch.setenv("LCMHIP_BIG256_N128", "0")
+    base = run_all()
+    monkeypatch.setenv("LCMHIP_BIG256_N128", "2")
+    monkeypatch.setenv("LCMHIP_BIG256_N128_LAYOUT", layout)
+    got = run_all()
+    lin = A.double().cpu() @ W.double().cpu().T
+    ref = lin + b.double().cpu()
+    scale = max(1.0, float(ref.abs().max()))
+    assert (got[0].double().cpu() - ref).abs().max() <= 3e-2 * scale
+    assert (got[2].double().cpu() - lin).abs().max() <= 2e-3 * scale
+    assert (got[3].double().cpu() - (res0.double().cpu() + gate.double().cpu() * ref)).abs().max() <= 2e-3 * max(1.0, float((gate.double().cpu() * ref).abs().max()))
+    for g, o in zip(got, base):
+        assert torch.equal(g, o)
+
+
 @pytest.mark.parametrize("M", [65, 96, 128])
 @pytest.mark.parametrize("N,K", [(5632, 2048), (6144, 256), (64, 256), (48 * 16, 768)])
 def test_gemm_swiglu_guarded_window(hip, M, N, K):
