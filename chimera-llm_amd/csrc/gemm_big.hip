@@ -33,10 +33,11 @@ __device__ __forceinline__ int big_select_matrix(GemmArgs& p, int bx, int tiles_
     if (p.stack > 1) {
         const int g = bx / tiles_per_matrix;
         bx -= g * tiles_per_matrix;
-        if (g > 0) {
-            p.W = p.stack_W[g - 1];
-            p.bias = p.stack_bias[g - 1];
-            p.out = p.stack_out[g - 1];
+        // constant indices only: a run-time index into the argument struct would move all of it to scratch memory
+        if (g == 1) {
+            p.W = p.stack_W[0]; p.bias = p.stack_bias[0]; p.out = p.stack_out[0];
+        } else if (g >= 2) {
+            p.W = p.stack_W[1]; p.bias = p.stack_bias[1]; p.out = p.stack_out[1];
         }
     }
     return bx;
@@ -321,8 +322,11 @@ constexpr int kBig256Lds = 2 * 4 * kHT;   // 128 KB
 // WT = weight-row tiles per wave: 4 (256 weight rows per tile, the description above) or 2 (a 256 x 128 tile for products
 // with too few 256 x 256 tiles: wave tile 128 x 32, one weight half-tile per K tile, 8 matrix-core instructions per
 // phase, the same barriers and hazards; linear epilogues only).
-template <int EPI, int WT>
+// HR (256-row weight tile only): the fragment reads are issued by hand (inline-asm ds_read_b128) and retired with counted
+// lgkmcnt waits instead of the compiler's, which drains every pending LDS read before a product that needs any.
+template <int EPI, int WT, bool HR = false>
 __global__ __launch_bounds__(512) void k_gemm_big256(GemmArgs p) {
+    static_assert(!HR || WT == 4, "hand-issued reads exist for the 256 x 256 tile only");
     constexpr bool DUAL = (EPI == LCMHIP_EPI_SWIGLU);
     static_assert(WT == 4 || (WT == 2 && !DUAL), "the 256 x 128 tile has no SwiGLU pairing");
     constexpr int BNW = 64 * WT;              // weight rows of the tile
@@ -352,8 +356,10 @@ __global__ __launch_bounds__(512) void k_gemm_big256(GemmArgs p) {
     // (r / 2) % 8 = 4 (w % 2) + (lane / 8) / 2 in both rounds.
     const int srow = lane >> 3;
     const uint32_t piece_off = (uint32_t)(((lane & 7) ^ ((4 * (wid & 1) + (srow >> 1)) & 7)) * 16);
-    uint32_t offX[2][2], offW[2][2];   // [half][round] byte offsets from p.A / p.W (p.W2)
-    bool w2[2][2];
+    // activation rows: [half][round] byte offsets from p.A (rows past the end are clamped, so they are not a uniform
+    // step apart); weight rows: one offset for (half 0, round 0), the others a uniform step further
+    uint32_t offX[2][2], offW0;
+    bool w2 = false;           // SwiGLU: this lane stages rows of the second matrix (the same in every half and round)
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -362,20 +368,24 @@ __global__ __launch_bounds__(512) void k_gemm_big256(GemmArgs p) {
             int m = m0 + 128 * h + r;
             m = m < p.M ? m : p.M - 1;                   // rows past the end repeat the last row; never stored
             offX[h][j] = (uint32_t)m * (uint32_t)p.lda * 2u + piece_off;
-            const int t = 128 * h + r;                   // weight row inside the tile
-            w2[h][j] = false;
-            if constexpr (DUAL) {
-                // wave column t / 64 owns 32 gate rows followed by 32 inner rows of the same 32 outputs
-                const int wcol = t >> 6, rr = t & 63;
-                offW[h][j] = (uint32_t)(bx * 128 + wcol * 32 + (rr & 31)) * kbytes + piece_off;
-                w2[h][j] = rr >= 32;
-            } else {
-                offW[h][j] = (uint32_t)(bx * BNW + t) * kbytes + piece_off;   // WT == 2: only half 0 is ever staged
-            }
         }
+    uint32_t w_step_j, w_step_h;                         // byte steps to round 1 / to half 1 (wave-uniform)
+    {
+        const int r = wid * 8 + srow;                    // weight row inside the tile: t = 128 h + 64 j + r
+        if constexpr (DUAL) {
+            // wave column t / 64 owns 32 gate rows followed by 32 inner rows of the same 32 outputs
+            offW0 = (uint32_t)(bx * 128 + (r & 31)) * kbytes + piece_off;
+            w2 = r >= 32;
+            w_step_j = 32u * kbytes;
+            w_step_h = 64u * kbytes;
+        } else {
+            offW0 = (uint32_t)(bx * BNW + r) * kbytes + piece_off;   // WT == 2: only half 0 is ever staged
+            w_step_j = 64u * kbytes;
+            w_step_h = 128u * kbytes;
+        }
+    }
     const char* const Ab = reinterpret_cast<const char*>(p.A);
-    const char* const Wb = reinterpret_cast<const char*>(p.W);
-    const char* const W2b = reinterpret_cast<const char*>(p.W2);
+    const char* const Wsel = reinterpret_cast<const char*>((DUAL && w2) ? p.W2 : p.W);
     auto stage_x = [&](int h, int kt, int buf) {
         char* dst = smem + buf * (4 * kHT) + h * kHT + wid * 1024;
         const uint32_t koff = (uint32_t)kt * kRowB;
@@ -385,12 +395,10 @@ __global__ __launch_bounds__(512) void k_gemm_big256(GemmArgs p) {
     };
     auto stage_w = [&](int h, int kt, int buf) {
         char* dst = smem + buf * (4 * kHT) + (2 + h) * kHT + wid * 1024;
-        const uint32_t koff = (uint32_t)kt * kRowB;
+        const uint32_t koff = (uint32_t)kt * kRowB + (uint32_t)h * w_step_h;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const char* base = (DUAL && w2[h][j]) ? W2b : Wb;
-            __builtin_amdgcn_global_load_lds((gptr_t)(base + offW[h][j] + koff), (lptr_t)(dst + j * 8192), 16, 0, 0);
-        }
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)(Wsel + offW0 + (koff + (uint32_t)j * w_step_j)), (lptr_t)(dst + j * 8192), 16, 0, 0);
     };
 
     f32x4 acc[WT][8];
@@ -444,6 +452,96 @@ __global__ __launch_bounds__(512) void k_gemm_big256(GemmArgs p) {
             acc[a][2 * (I) + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[KS][a], XF[KS][b], acc[a][2 * (I) + b], 0, 0, 0);
 
     bf16x8 w[2][WT], xe[2][2], xo[2][2];
+    if constexpr (HR) {
+        // Reads retire in order, so "at most n younger reads pending" retires a fragment.  The compiler does not know that
+        // an asm result is still in flight: every wait is followed by a scheduling fence so that no product moves above
+        // it, and nothing copies a fragment -- the next K tile's weight fragments are read IN PLACE, each pair of weight
+        // tiles right behind its last products of phase 3 (tiles 0-1 first, then 2-3), and retired by the counted waits
+        // of the next tile's phase 0.  LDS reads per phase: 4 / 4 / 4 / 12, as with the compiler-issued reads.
+        //   phase 0: read X1 | DMA X-half 1 of kt+1 | retire X0, W01 (8 younger) | products W01 | retire W23 (4) | products W23
+        //   phase 1: barrier A | read X2 | DMA W-half 0 of kt+2 | retire X1 (4) | 16 products
+        //   phase 2: read X3 | DMA W-half 1 of kt+2 | retire X2 (4) | 16 products
+        //   phase 3: vmcnt, lgkmcnt(0), barrier B | DMA X-half 0 of kt+2 | read X0' | products W01 | read W01' | products W23 | read W23'
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+        // fragment bases of K-tile buffer 0; buffer 1 is 64 KB further (beyond the 16-bit offset field: added per read)
+        const uint32_t xb0 = lds0 + (uint32_t)(x_off + slot0), xb1 = lds0 + (uint32_t)(x_off + slot1);
+        const uint32_t wb0 = lds0 + (uint32_t)(w_off + slot0), wb1 = lds0 + (uint32_t)(w_off + slot1);
+#define LCM_DSR(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "i"(OFF))
+#define LCM_LGKM(N) asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : "memory")
+#define LCM_HPIN() __builtin_amdgcn_sched_barrier(0)
+#define LCM_HRD_X2(DST, BUF, I)                                                      \
+    _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                  \
+        LCM_DSR(DST[0][b], xb0 + (BUF) * (4u * kHT), (2 * (I) + b) * 16 * kRowB);    \
+        LCM_DSR(DST[1][b], xb1 + (BUF) * (4u * kHT), (2 * (I) + b) * 16 * kRowB);    \
+    }
+#define LCM_HRD_W2(BUF, TN0)                                                         \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                  \
+        LCM_DSR(w[0][TN0 + a], wb0 + (BUF) * (4u * kHT), ((TN0) + a) * 16 * kRowB);  \
+        LCM_DSR(w[1][TN0 + a], wb1 + (BUF) * (4u * kHT), ((TN0) + a) * 16 * kRowB);  \
+    }
+#define LCM_HMMA8(TN0, XF, I)                    \
+    __builtin_amdgcn_s_setprio(1);               \
+    LCM_MMA8(TN0, XF, I)                         \
+    __builtin_amdgcn_s_setprio(0);
+#define LCM_HTILE(BUF, KT, MORE1, MORE2)                                                               \
+    {                                                                                                  \
+        LCM_HRD_X2(xo, BUF, 1)                                                                         \
+        if (MORE1) stage_x(1, (KT) + 1, (BUF) ^ 1);                                                    \
+        LCM_LGKM(8);                                                                                   \
+        LCM_HPIN();                                                                                    \
+        LCM_HMMA8(0, xe, 0)                                                                            \
+        LCM_HPIN();                                                                                    \
+        LCM_LGKM(4);                                                                                   \
+        LCM_HPIN();                                                                                    \
+        LCM_HMMA8(2, xe, 0)                                                                            \
+        LCM_HPIN();                                                                                    \
+        __builtin_amdgcn_s_barrier();                                                                  \
+        LCM_HRD_X2(xe, BUF, 2)                                                                         \
+        if (MORE2) stage_w(0, (KT) + 2, BUF);                                                          \
+        LCM_LGKM(4);                                                                                   \
+        LCM_HPIN();                                                                                    \
+        LCM_HMMA8(0, xo, 1)                                                                            \
+        LCM_HMMA8(2, xo, 1)                                                                            \
+        LCM_HPIN();                                                                                    \
+        LCM_HRD_X2(xo, BUF, 3)                                                                         \
+        if (MORE2) stage_w(1, (KT) + 2, BUF);                                                          \
+        LCM_LGKM(4);                                                                                   \
+        LCM_HPIN();                                                                                    \
+        LCM_HMMA8(0, xe, 2)                                                                            \
+        LCM_HMMA8(2, xe, 2)                                                                            \
+        LCM_HPIN();                                                                                    \
+        if (MORE2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                    \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
+        LCM_LGKM(0);                                                                                   \
+        __builtin_amdgcn_s_barrier();                                                                  \
+        if (MORE2) stage_x(0, (KT) + 2, BUF);                                                          \
+        if (MORE1) { LCM_HRD_X2(xe, (BUF) ^ 1, 0) }                                                    \
+        LCM_HPIN();                                                                                    \
+        LCM_HMMA8(0, xo, 3)                                                                            \
+        LCM_HPIN();                                                                                    \
+        if (MORE1) { LCM_HRD_W2((BUF) ^ 1, 0) }                                                        \
+        LCM_HPIN();                                                                                    \
+        LCM_HMMA8(2, xo, 3)                                                                            \
+        LCM_HPIN();                                                                                    \
+        if (MORE1) { LCM_HRD_W2((BUF) ^ 1, 2) }                                                        \
+    }
+        LCM_HRD_X2(xe, 0, 0)
+        LCM_HRD_W2(0, 0)
+        LCM_HRD_W2(0, 2)
+        for (int kt = 0; kt < nk - 2; kt += 2) {     // nk is even: K is a multiple of 128
+            LCM_HTILE(0, kt, true, true)
+            LCM_HTILE(1, kt + 1, true, true)
+        }
+        LCM_HTILE(0, nk - 2, true, false)
+        LCM_HTILE(1, nk - 1, false, false)
+#undef LCM_HTILE
+#undef LCM_HMMA8
+#undef LCM_HRD_W2
+#undef LCM_HRD_X2
+#undef LCM_HPIN
+#undef LCM_LGKM
+#undef LCM_DSR
+    } else {
     LCM_RD_X2(xe, smem, 0)
     LCM_RD_W2(smem, 0)
     if constexpr (WT == 4) LCM_RD_W2(smem, 2)
@@ -589,6 +687,7 @@ __global__ __launch_bounds__(512) void k_gemm_big256(GemmArgs p) {
     for (int kt = 0; kt < nk - 2; ++kt) tile(kt, yes{}, yes{});
     tile(nk - 2, yes{}, no{});
     tile(nk - 1, no{}, no{});
+    }
 #undef LCM_PIN
 #undef LCM_RD_W2
 #undef LCM_RD_X2
@@ -867,14 +966,26 @@ static int launch_gemm_big256(const GemmArgs& a_in, int epi, int m_rows, int wt,
     a.tiles_x = wrows / (64 * wt);
     a.tiles_y = (m_rows + 255) / 256;
     dim3 grid(a.tiles_x * a.tiles_y), block(512);
-#define LCM_BIG256(E, W)                                                                                           \
+#define LCM_BIG256_3(E, W, H)                                                                                      \
     {                                                                                                              \
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_big256<E, W>),    \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_big256<E, W, H>), \
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, kBig256Lds); \
         LCM_HIP_CHECK(attr);                                                                                       \
-        hipLaunchKernelGGL((k_gemm_big256<E, W>), grid, block, kBig256Lds, st, a);                                 \
+        hipLaunchKernelGGL((k_gemm_big256<E, W, H>), grid, block, kBig256Lds, st, a);                              \
     }
-    if (wt == 4) {
+#define LCM_BIG256(E, W) LCM_BIG256_3(E, W, false)
+    const char* he = getenv("LCMHIP_BIG256_HR");      // hand-issued fragment reads (read per call); needs K % 128 == 0
+    const bool hr = (he ? atoi(he) != 0 : false) && a.K % 128 == 0;
+    if (wt == 4 && hr) {
+        switch (epi) {
+            case LCMHIP_EPI_STORE: LCM_BIG256_3(LCMHIP_EPI_STORE, 4, true); break;
+            case LCMHIP_EPI_STORE_F32: LCM_BIG256_3(LCMHIP_EPI_STORE_F32, 4, true); break;
+            case LCMHIP_EPI_RELU: LCM_BIG256_3(LCMHIP_EPI_RELU, 4, true); break;
+            case LCMHIP_EPI_SWIGLU: LCM_BIG256_3(LCMHIP_EPI_SWIGLU, 4, true); break;
+            case LCMHIP_EPI_RESID: LCM_BIG256_3(LCMHIP_EPI_RESID, 4, true); break;
+            default: return fail(LCMHIP_ERR_INVALID, "gemm: unknown epilogue");
+        }
+    } else if (wt == 4) {
         switch (epi) {
             case LCMHIP_EPI_STORE: LCM_BIG256(LCMHIP_EPI_STORE, 4); break;
             case LCMHIP_EPI_STORE_F32: LCM_BIG256(LCMHIP_EPI_STORE_F32, 4); break;
@@ -914,6 +1025,7 @@ static int launch_gemm_big256(const GemmArgs& a_in, int epi, int m_rows, int wt,
 #undef LCM_BIG256X128
     }
 #undef LCM_BIG256
+#undef LCM_BIG256_3
     LCM_HIP_CHECK(hipGetLastError());
     return LCMHIP_OK;
 }

@@ -62,6 +62,38 @@ def ab_n128():
         print(f"M={M} N={N} K={K} epi={epi}: 128x128 kernel {a:7.1f} us, 256x128 tile {b:7.1f} us  ({100 * (a / b - 1):+.1f} %)", flush=True)
     os.environ.pop("LCMHIP_BIG256_N128", None)
 
+def ab_env(var, on, shapes, label_off, label_on, iters=50):
+    """One environment switch of the library (read at every launch), alternating inside one process."""
+    for M, N, K, epi in shapes:
+        A = torch.randn(M, K, device=dev).bfloat16()
+        W = (torch.randn(N, K, device=dev) * 0.02).bfloat16()
+        W2 = (torch.randn(N, K, device=dev) * 0.02).bfloat16() if epi == _hip.EPI_SWIGLU else None
+        out = torch.zeros(M, N, device=dev, dtype=torch.float32 if epi == _hip.EPI_RESID else torch.bfloat16)
+        res = {}
+        for rnd in range(3):
+            for mode in ("0", on):
+                os.environ[var] = mode
+                def run():
+                    _hip.check(_hip.lib.lcmhip_gemm(_hip.ptr(A), K, _hip.ptr(W), _hip.ptr(W2), None, None, None, _hip.ptr(out), N,
+                                                    M, N, K, epi, _hip.BF16, None, 0, st))
+                for _ in range(3): run()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(iters): run()
+                e1.record(); torch.cuda.synchronize()
+                res.setdefault(mode, []).append(1e3 * e0.elapsed_time(e1) / iters)
+        a, b = min(res["0"]), min(res[on])
+        fl = 2.0 * M * N * K * (2 if epi == _hip.EPI_SWIGLU else 1)
+        print(f"M={M} N={N} K={K} epi={epi}: {label_off} {a:7.1f} us ({fl / a / 1e6:6.0f} TF), {label_on} {b:7.1f} us ({fl / b / 1e6:6.0f} TF)  ({100 * (a / b - 1):+.1f} %)", flush=True)
+    os.environ.pop(var, None)
+
+if os.environ.get("GB_AB_HR"):
+    ab_env("LCMHIP_BIG256_HR", "1", [(4096, 5632, 2048, _hip.EPI_SWIGLU), (1024, 5632, 2048, _hip.EPI_SWIGLU), (4096, 4096, 4096, _hip.EPI_STORE),
+                                     (2304, 6400, 2048, _hip.EPI_STORE), (4096, 4096, 2048, _hip.EPI_RESID), (8192, 8192, 8192, _hip.EPI_STORE)],
+           "compiler-issued reads", "hand-issued reads", iters=20)
+    sys.exit(0)
+
 if os.environ.get("GB_AB_N128"):
     pr = torch.cuda.get_device_properties(0)
     print(f"device: {pr.name}, {pr.multi_processor_count} CUs, clock {getattr(pr, 'clock_rate', 0) / 1e3:.0f} MHz, "
