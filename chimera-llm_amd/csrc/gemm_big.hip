@@ -944,20 +944,20 @@ static bool big256_applicable(const GemmArgs& a, int epi, int splits, int m_rows
     return ratio10 * waves256 < 10 * waves128;
 }
 
-// The 256 x 128 tile (wave tile 128 x 32) for linear products whose 256 x 256 tiles would leave CUs idle.
-// LCMHIP_BIG256_N128: 0 = never, 1 = when its tiles fill at least 3/4 of one wave of CUs and the 256 x 256 kernel does not
-// apply (default, see the measurements at the routing below), 2 = whenever the shape allows (measurements).
+// The 256 x 128 tile for linear products without a K split that the 256 x 256 kernel does not take: it replaces the
+// 128 x 128 kernel there (the same wave quantisation: one 256 x 128 tile per CU is two 128 x 128 tiles per CU).  In-process
+// A/B against the 128 x 128 kernel at 4096 rows, slower / faster device class of the pool: 2048 x 2048 store +9..13 % /
+// +1 %, 2048 x 5632 store +12 % / +13 %, residual update 2048 x 2048 +9..10 % / +16 %, 2048 x 5632 +12 % / +16 %,
+// stacked q / k / v (6144 x 2048) +5 % / +8 %; 2048^3 +6 % / +7 %.  Results are bit-identical (same K order per output).
+// LCMHIP_BIG256_N128 = 0 turns it off (read at every launch: the A/B script switches it inside one process).
 static bool big256n128_applicable(const GemmArgs& a, int epi, int splits, int m_rows) {
-    const char* e = getenv("LCMHIP_BIG256_N128");   // read per call: the A/B script switches it inside one process
-    const int mode = e ? atoi(e) : 0;
+    const char* e = getenv("LCMHIP_BIG256_N128");
+    const int mode = e ? atoi(e) : 1;
     if (mode == 0 || splits != 1 || epi == EPI_PARTIAL || epi == LCMHIP_EPI_SWIGLU) return false;
     if (a.N % 128 != 0 || a.K % 128 != 0 || a.K < 256) return false;   // the K loop runs in pairs of 64-wide tiles
-    const int wrows = a.N * std::max(1, a.stack);
-    if ((size_t)a.M * a.lda * 2 >= (1ull << 31) || (size_t)a.N * a.K * 2 >= (1ull << 31)) return false;
-    const int tiles = (wrows / 128) * ((m_rows + 255) / 256);
-    if (mode >= 2) return true;
-    const int rem = tiles % 256;
-    return tiles >= 192 && (rem == 0 || rem >= 192);
+    if ((size_t)a.M * a.lda * 2 >= (1ull << 31) || (size_t)a.N * a.K * 2 >= (1ull << 31)) return false;   // 32-bit offsets
+    (void)m_rows;
+    return true;
 }
 
 static int launch_gemm_big256(const GemmArgs& a_in, int epi, int m_rows, int wt, hipStream_t st) {

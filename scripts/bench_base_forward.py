@@ -45,11 +45,11 @@ if os.environ.get("BF_AB"):
 # 128 x 128 kernel, alternating in one process (the library reads LCMHIP_BIG256_N128 at every launch)
 if os.environ.get("BF_AB_N128"):
     for rnd in range(3):
-        for mode in ("0", "2"):
+        for mode in ("0", "1"):
             os.environ["LCMHIP_BIG256_N128"] = mode
             dt, _ = measure(10)
             print(f"round {rnd} LCMHIP_BIG256_N128={mode}: {dt * 1e3:.2f} ms per forward", flush=True)
-    os.environ["LCMHIP_BIG256_N128"] = os.environ.get("BF_N128_FINAL", "0")
+    os.environ["LCMHIP_BIG256_N128"] = os.environ.get("BF_N128_FINAL", "1")
 dt, out = measure(int(os.environ.get("BF_STEPS", "10")))
 assert torch.isfinite(out).all()
 d, F, L, H = cfg.model_dim, cfg.lcm.allocated_ffn_dim(), cfg.lcm.num_layers, cfg.lcm.num_attn_heads

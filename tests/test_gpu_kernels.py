@@ -120,9 +120,9 @@ def test_gemm_one_tile_per_cu(hip, M, K):
 @pytest.mark.parametrize("layout", ["0", "1"])
 @pytest.mark.parametrize("M,N,K", [(4096, 2048, 2048), (4000, 2048, 768), (3700, 6144, 256), (513, 1280, 5632)])
 def test_gemm_256x128_tile(hip, monkeypatch, M, N, K, layout):
-    """The 256 x 128 tile kernels (LCMHIP_BIG256_N128=2; layout 0: wave tile 64 x 64 with hand-issued fragment reads and
+    """The 256 x 128 tile kernels (the default routing of linear many-row products without a K split; layout 0: wave tile 64 x 64 with hand-issued fragment reads and
     counted waits, layout 1: wave tile 128 x 32) against float64 through every linear epilogue, and bit for bit against
-    the default routing: every output sums its K tiles in the same order in all of these kernels.  Ragged row counts,
+    the 128 x 128 kernel (LCMHIP_BIG256_N128=0): every output sums its K tiles in the same order in all of these kernels.  Ragged row counts,
     the shortest K loop the interface allows (4 K tiles), several waves of tiles."""
     import os
     dt = torch.bfloat16
@@ -150,7 +150,7 @@ def test_gemm_256x128_tile(hip, monkeypatch, M, N, K, layout):
 
     monkeypatch.setenv("LCMHIP_BIG256_N128", "0")
     base = run_all()
-    monkeypatch.setenv("LCMHIP_BIG256_N128", "2")
+    monkeypatch.setenv("LCMHIP_BIG256_N128", "1")
     monkeypatch.setenv("LCMHIP_BIG256_N128_LAYOUT", layout)
     got = run_all()
     lin = A.double().cpu() @ W.double().cpu().T
