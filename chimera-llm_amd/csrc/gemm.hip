@@ -294,6 +294,12 @@ static Plan make_plan(const GemmArgs& a, bool may_split) {
 // The LDS image is lane-linear, so bank conflicts of the fragment reads (16 rows x one 16-byte piece) are removed on
 // the SOURCE side: slot s of tile row r holds K piece s ^ (r % 16).
 // ------------------------------------------------------------------------------------------------
+#ifndef LCM_DMA_ROTATE
+#define LCM_DMA_ROTATE 1                             // 0: every workgroup walks K from its first chunk (A/B builds)
+#endif
+#ifndef LCM_DMA_INTERLEAVE
+#define LCM_DMA_INTERLEAVE 1                         // 0: the DMA of a chunk as one burst behind the barrier (A/B builds)
+#endif
 constexpr int kDmaChunk = 256;                       // bytes of K per tile row and stage
 constexpr int dma_stage_bytes(int wm) { return (32 * wm + 64) * kDmaChunk; }   // activation rows + 64 weight rows
 constexpr int dma_lds_bytes(int wm) { return 3 * dma_stage_bytes(wm); }         // 144 KB (128 rows) / 96 KB (64 rows)
@@ -347,9 +353,18 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_dma(GemmArgs p) {
             }
         }
     }
+#if LCM_DMA_ROTATE
+    // A workgroup walks its K range from a chunk of its own and wraps around: the workgroups of an XCD (ids i, i + 8,
+    // ...) all read the SAME activation chunk from their L2 at about the same time otherwise (every one of them needs the
+    // whole row tile), and those reads queue on the few L2 channels that hold it.
+    const int rot = nc > 1 ? (int)(((blockIdx.x >> 3) * 3u + (blockIdx.x & 7u)) % (unsigned)nc) : 0;
+    auto chunk_of = [&](int c) { const int r = c + rot; return r >= nc ? r - nc : r; };
+#else
+    auto chunk_of = [&](int c) { return c; };
+#endif
     auto stage = [&](int c, int buf) {
         char* dst = smem + buf * kDmaStage + wid * 1024;
-        const uint32_t koff = (uint32_t)c * kDmaChunk;
+        const uint32_t koff = (uint32_t)chunk_of(c) * kDmaChunk;
 #pragma unroll
         for (int j = 0; j < XJ; ++j)
             __builtin_amdgcn_global_load_lds((dma_gptr_t)(src[j] + koff), (dma_lptr_t)(dst + j * NW * 1024), 16, 0, 0);
@@ -372,6 +387,53 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_dma(GemmArgs p) {
 
     stage(0, 0);
     if (nc > 1) stage(1, 1);
+#if LCM_DMA_INTERLEAVE
+    // one DMA instruction of chunk c + 2 (piece j of this wave)
+    auto stage_piece = [&](int c, int buf, int j) {
+        char* dst = smem + buf * kDmaStage + wid * 1024 + j * NW * 1024;
+        const uint32_t koff = (uint32_t)chunk_of(c) * kDmaChunk;
+        if (NT && j >= XJ) __builtin_amdgcn_global_load_lds((dma_gptr_t)(src[j] + koff), (dma_lptr_t)dst, 16, 0, 2);
+        else __builtin_amdgcn_global_load_lds((dma_gptr_t)(src[j] + koff), (dma_lptr_t)dst, 16, 0, 0);
+    };
+    for (int c = 0; c < nc; ++c) {
+        if (c + 1 < nc) {
+            if constexpr (NG == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        const char* base = smem + (c % 3) * kDmaStage;
+        const bool more = c + 2 < nc;
+        const int nbuf = (c + 2) % 3;
+        // the DMA of chunk c + 2 is spread over the four k-steps (behind each step's fragment reads) instead of one burst
+        // behind the barrier, where every wave of the CU queues its instructions at the same moment
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 w[2], x[2];
+            const int slot = ((4 * ks + kq) ^ frow) * 16;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) w[t] = *reinterpret_cast<const bf16x8*>(base + w_off + t * 16 * kDmaChunk + slot);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) x[t] = *reinterpret_cast<const bf16x8*>(base + x_off + t * 16 * kDmaChunk + slot);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+                constexpr int per = NG / 4, extra = NG % 4;     // NG = 6: 2, 2, 1, 1 pieces; NG = 8: 2 each
+                const int first = ks * per + (ks < extra ? ks : extra);
+                const int count = per + (ks < extra ? 1 : 0);
+#pragma unroll
+                for (int j = 0; j < count; ++j) stage_piece(c + 2, nbuf, first + j);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[tn], x[tm], acc[tn][tm], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#else
     for (int c = 0; c < nc; ++c) {
         // chunk c has landed (this wave's part: everything but the NG newest DMA instructions = chunk c + 1) ...
         if (c + 1 < nc) {
@@ -401,6 +463,7 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_dma(GemmArgs p) {
                 for (int tm = 0; tm < 2; ++tm)
                     acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ks][tn], x[ks][tm], acc[tn][tm], 0, 0, 0);
     }
+#endif
     gemm_epilogue<bf16_t, EPI, 2, 2>(p, acc, m0 + wm * 32, DUAL ? blockIdx.x * 32 + wn * 16 : blockIdx.x * 64 + wn * 32,
                                      blockIdx.y, lane);
 }
