@@ -277,7 +277,11 @@ static Plan make_plan(const GemmArgs& a, bool may_split) {
         s = std::min(s, nchunks);
         // the LDS-DMA tall tile wants at least two 512-byte chunks per split (four stages of its pipeline):
         // measured 10.6 -> 10.1 us on 128 x 2048 x 2048; the 64-row tile is faster with one (7.1 vs 7.7 us)
-        if (pl.wm == 4 && a.dtype == LCMHIP_BF16 && dma_mode() != 0) s = std::min(s, std::max(1, nchunks / 2));
+        // (LCMHIP_TALL_MIN_CHUNKS; re-measured with the DMA spread over the k-steps: one chunk per split makes self_ov itself
+        // 9 % faster, 6.2 against 6.9 us, and the whole loop 1.5 % slower, 1313 against 1333 sentence-embeddings/s: twice the
+        // slabs for the next norm kernel)
+        static const int tall_min = [] { const char* e = getenv("LCMHIP_TALL_MIN_CHUNKS"); return e ? std::max(1, atoi(e)) : 2; }();
+        if (pl.wm == 4 && a.dtype == LCMHIP_BF16 && dma_mode() != 0) s = std::min(s, std::max(1, nchunks / tall_min));
         s = std::min(s, a.max_splits > 0 ? a.max_splits : 64);
         pl.splits = std::max(1, s);
         // re-balance: every split gets the same number of chunks where possible
