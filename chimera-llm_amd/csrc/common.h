@@ -199,7 +199,17 @@ struct GemmArgs {
     // epilogues without a K split only; every output shares ldo, out_rows and out_head_cap.
     int stack;
     const void* stack_W[2]; const void* stack_bias[2]; void* stack_out[2];
+    // Per-matrix epilogue switches of a stacked product (bit g = matrix g; many-row kernels, operand-dtype STORE only):
+    //  scatter_mask: matrices whose rows go through out_rows / out_head_cap (0: all of them, the plain meaning of out_rows);
+    //  rope_mask:    matrices whose outputs are rotated after the store rounding -- consecutive pairs (2i, 2i + 1) of every
+    //                128-wide head by the angle row rope_pos[m] of the cos / sin tables ([position][64]), as k_rope_store does.
+    int scatter_mask, rope_mask;
+    const int32_t* rope_pos; const float* rope_cos; const float* rope_sin;
+    int stack_sel;              // set by the kernels: the matrix of the workgroup's tile
 };
+// True when launch_gemm would run this stacked product as ONE launch of a many-row kernel (whose epilogue knows the
+// per-matrix switches above); otherwise it runs one product per matrix and the switches must not be set.
+bool gemm_stack_is_fused(const GemmArgs& a);
 // C = A W^T with the epilogue applied (split-K + finishing pass when a.partial is given and it pays).
 int launch_gemm(const GemmArgs& a, hipStream_t st);
 // Raw partial products only: slab [*splits][M][N] in a.partial, to be summed by the consumer.
@@ -309,6 +319,14 @@ int launch_fill_rows(void* cache, const void* vec, const int32_t* rows_idx, int 
 __host__ __device__ inline size_t kv_cache_offset(int r, int n, int cap, int d) {
     const int slot = r / cap, pos = r % cap;
     return (((size_t)slot * (d >> 7) + (n >> 7)) * cap + pos) * 128 + (n & 127);
+}
+// Rotation of one pair (x0, x1) by the angle whose cosine / sine are cs / sn.  Every product and sum is rounded on its
+// own (no contraction into fused multiply-adds), so that every kernel that rotates gives the same bits.
+__device__ __forceinline__ void rope_rotate(float& x0, float& x1, float cs, float sn) {
+#pragma clang fp contract(off)
+    const float a = x0 * cs, b = x1 * sn, c = x0 * sn, d = x1 * cs;
+    x0 = a - b;
+    x1 = c + d;
 }
 int launch_finalize_step(const float* new_emb, void* seqs, int dtype, const int32_t* doc_rows, const int32_t* prompt_lens,
                          int n_active, int step, int total_len, int dim, const float* eos, float* cos_out, hipStream_t st);

@@ -1145,11 +1145,8 @@ __global__ __launch_bounds__(256) void k_rope_store(T* __restrict__ q, const T* 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float cs = cos_tab[pos * 64 + pair0 + j], sn = sin_tab[pos * 64 + pair0 + j];
-                const float q0 = qv[2 * j], q1 = qv[2 * j + 1], k0 = kv[2 * j], k1 = kv[2 * j + 1];
-                qv[2 * j] = q0 * cs - q1 * sn;
-                qv[2 * j + 1] = q0 * sn + q1 * cs;
-                kv[2 * j] = k0 * cs - k1 * sn;
-                kv[2 * j + 1] = k0 * sn + k1 * cs;
+                rope_rotate(qv[2 * j], qv[2 * j + 1], cs, sn);
+                rope_rotate(kv[2 * j], kv[2 * j + 1], cs, sn);
             }
             if (q != nullptr) store8<T>(q + src + c, qv);
         }

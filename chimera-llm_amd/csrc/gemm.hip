@@ -586,6 +586,10 @@ int launch_gemm_partial(const GemmArgs& a, int* splits, hipStream_t st) {
     return a.dtype == LCMHIP_BF16 ? launch_plan<bf16_t>(a, pl, EPI_PARTIAL, st) : launch_plan<float>(a, pl, EPI_PARTIAL, st);
 }
 
+bool gemm_stack_is_fused(const GemmArgs& a) {
+    return a.stack > 1 && a.stack <= 3 && check_args(a) == LCMHIP_OK && gemm_big_applicable(a, false);
+}
+
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
     LCM_TRY(check_args(a));
     LCM_REQUIRE(a.out != nullptr && a.ldo % 4 == 0 && ((uintptr_t)a.out % 16) == 0, "gemm: output must be 16-byte aligned");
@@ -595,6 +599,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
         LCM_REQUIRE(a.stack <= 3 && (a.epilogue == LCMHIP_EPI_STORE || a.epilogue == LCMHIP_EPI_STORE_F32 || a.epilogue == LCMHIP_EPI_RELU),
                     "gemm: stacked products take up to 3 matrices and a linear epilogue");
         if (gemm_big_applicable(a, false)) return launch_gemm_big(a, a.epilogue, 1, a.M, st);
+        LCM_REQUIRE(a.rope_mask == 0 && a.scatter_mask == 0, "gemm: per-matrix epilogue switches need the single-launch form (gemm_stack_is_fused)");
         for (int g = 0; g < a.stack; ++g) {
             GemmArgs one = a;
             one.stack = 0;

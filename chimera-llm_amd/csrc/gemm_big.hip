@@ -30,9 +30,11 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // Stacked products: the weight-row tile index counts through all matrices.  Selects the tile's matrix (weight, bias,
 // output) in the workgroup's copy of the arguments and returns the tile index inside that matrix.
 __device__ __forceinline__ int big_select_matrix(GemmArgs& p, int bx, int tiles_per_matrix) {
+    p.stack_sel = 0;
     if (p.stack > 1) {
         const int g = bx / tiles_per_matrix;
         bx -= g * tiles_per_matrix;
+        p.stack_sel = g;
         // constant indices only: a run-time index into the argument struct would move all of it to scratch memory
         if (g == 1) {
             p.W = p.stack_W[0]; p.bias = p.stack_bias[0]; p.out = p.stack_out[0];
@@ -172,15 +174,31 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& p, const f32x4 (&ac
                 const float4 a = *reinterpret_cast<const float4*>(tile + r * LROW + c);
                 const float4 b = *reinterpret_cast<const float4*>(tile + r * LROW + c + 4);
                 if (m < p.M) {
+                    const bool scatter = p.out_rows != nullptr && (p.scatter_mask == 0 || ((p.scatter_mask >> p.stack_sel) & 1));
                     size_t oidx;
-                    if (p.out_rows == nullptr) oidx = (size_t)m * p.ldo + n;
+                    if (!scatter) oidx = (size_t)m * p.ldo + n;
                     else if (p.out_head_cap > 0) oidx = kv_cache_offset(p.out_rows[m], n, p.out_head_cap, p.N);
                     else oidx = (size_t)p.out_rows[m] * p.ldo + n;
+                    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                    if constexpr (EPI == LCMHIP_EPI_STORE) {
+                        if ((p.rope_mask >> p.stack_sel) & 1) {
+                            // the projection's output is rounded to the operand dtype first (as a separate rotation pass
+                            // would read it), rotated in fp32, and rounded again by the store
+                            const int pos = p.rope_pos[m], pair0 = (n & 127) >> 1;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float cs = p.rope_cos[pos * 64 + pair0 + j], sn = p.rope_sin[pos * 64 + pair0 + j];
+                                v[2 * j] = bf16_to_f32(f32_to_bf16(v[2 * j]));
+                                v[2 * j + 1] = bf16_to_f32(f32_to_bf16(v[2 * j + 1]));
+                                rope_rotate(v[2 * j], v[2 * j + 1], cs, sn);
+                            }
+                        }
+                    }
                     uint4 o;
-                    o.x = (uint32_t)f32_to_bf16(a.x) | ((uint32_t)f32_to_bf16(a.y) << 16);
-                    o.y = (uint32_t)f32_to_bf16(a.z) | ((uint32_t)f32_to_bf16(a.w) << 16);
-                    o.z = (uint32_t)f32_to_bf16(b.x) | ((uint32_t)f32_to_bf16(b.y) << 16);
-                    o.w = (uint32_t)f32_to_bf16(b.z) | ((uint32_t)f32_to_bf16(b.w) << 16);
+                    o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                    o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                    o.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+                    o.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
                     *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.out) + oidx) = o;
                 }
             }

@@ -202,6 +202,7 @@ struct lcmhip_session {
     bool keep_context = false;
     char* init_bias_pos = nullptr;  // initial_proj bias + position 0 of the denoiser's learned positions (operand dtype)
     bool stack_products = true;     // q / k / v (and cross k / v) of many rows in one launch; LCMHIP_STACK=0 turns it off
+    bool fuse_rope_store = true;    // ... with the rotation and the cache scatter in its epilogue; LCMHIP_FUSE_ROPE=0 turns it off
     // carved device buffers
     int32_t *slot_map = nullptr, *pos_rows = nullptr, *self_rows = nullptr, *cross_rows = nullptr, *slot0_rows = nullptr;
     char *self_k = nullptr, *self_v = nullptr, *cross_k = nullptr, *cross_v = nullptr;
@@ -506,6 +507,33 @@ static int gemm_stack(lcmhip_session* s, const char* tag, const void* A, int lda
     return LCMHIP_OK;
 }
 
+// Self-attention q / k / v of many rows with the rotation and the cache scatter in the product's epilogue: q lands
+// rotated in `q_out`, k (rotated) and v directly in the layer's cache rows.  Returns false (nothing launched) when the
+// product would not run as one launch of a many-row kernel; the caller then takes the separate passes.
+static bool qkv_rope_store_fused(lcmhip_session* s, const char* tag, const void* A, int lda, const AttnW& w, void* q_out,
+                                 void* k_cache, void* v_cache, int M, int cap, bool rope, hipStream_t st, int* rc) {
+    const Lin* const W[3] = {&w.q, &w.k, &w.v};
+    GemmArgs a = gemm_args(s, A, lda, *W[0], nullptr, M, LCMHIP_EPI_STORE);
+    if (!s->fuse_rope_store || !s->stack_products || a.dtype != LCMHIP_BF16) return false;
+    a.out = q_out; a.ldo = a.N; a.out_rows = s->self_rows; a.out_head_cap = cap;
+    a.partial = s->slab_q; a.partial_bytes = s->slab_bytes;
+    void* const outs[3] = {q_out, k_cache, v_cache};
+    for (int g = 1; g < 3; ++g) {
+        if (W[g]->out != W[0]->out || W[g]->in != W[0]->in || (W[g]->b != nullptr) != (W[0]->b != nullptr)) return false;
+        a.stack_W[g - 1] = W[g]->w; a.stack_bias[g - 1] = W[g]->b; a.stack_out[g - 1] = outs[g];
+    }
+    a.stack = 3;
+    a.scatter_mask = 0b110;
+    a.rope_mask = rope ? 0b011 : 0;
+    a.rope_pos = s->pos_rows; a.rope_cos = s->rope_cos; a.rope_sin = s->rope_sin;
+    if (a.N % 128 != 0 || !gemm_stack_is_fused(a)) return false;
+    double bytes, flops;
+    gemm_cost(a, (double)dtype_size(a.dtype), &bytes, &flops);
+    ProfScope ps(&s->prof, tag, bytes * 3, flops * 3, st);
+    *rc = launch_gemm(a, st);
+    return true;
+}
+
 // Product left in slab_p for the next norm kernel to fold into the residual stream.
 static int gemm_pending(lcmhip_session* s, const char* tag, const void* A, int lda, const Lin& W, const float* gate,
                         int M, Pending* pend, hipStream_t st, float* slab = nullptr) {
@@ -704,6 +732,8 @@ static int session_dims(lcmhip_session* s, const lcmhip_model* m, int max_batch,
     {
         const char* e = getenv("LCMHIP_STACK");
         s->stack_products = !(e && e[0] == '0');
+        e = getenv("LCMHIP_FUSE_ROPE");
+        s->fuse_rope_store = !(e && e[0] == '0');
     }
     return LCMHIP_OK;
 }
@@ -964,13 +994,18 @@ static int append_impl(lcmhip_session* s, const float* x, int32_t n_tokens, int3
             for (int l = 0; l < tc.num_layers; ++l) {
                 const CtxLayer& L = m->ctx[l];
                 LCM_TRY(norm(s, "ctx.norm", s->xres, L.sa_norm, nullptr, nullptr, s->act_a, R, R, tc.norm_kind, nullptr, st));
-                {
-                    const Lin* const w3[3] = {&L.sa.q, &L.sa.k, &L.sa.v};
-                    void* const o3[3] = {s->act_q, s->act_k, s->act_v};
-                    LCM_TRY(gemm_stack(s, "ctx.qkv", s->act_a, dm, 3, w3, o3, dm, R, st));
-                }
-                if (tc.qk_layernorm) LCM_TRY(qk_norm(s, "ctx.qk_norm", tc, L.sa, s->act_q, s->act_k, R, st));
-                {
+                int rc = LCMHIP_OK;
+                if (!tc.qk_layernorm &&
+                    qkv_rope_store_fused(s, "ctx.qkv_rope", s->act_a, dm, L.sa, s->act_q, s->self_k + l * self_layer,
+                                         s->self_v + l * self_layer, R, s->cap, tc.pos_kind == LCMHIP_POS_ROPE, st, &rc)) {
+                    LCM_TRY(rc);
+                } else {
+                    {
+                        const Lin* const w3[3] = {&L.sa.q, &L.sa.k, &L.sa.v};
+                        void* const o3[3] = {s->act_q, s->act_k, s->act_v};
+                        LCM_TRY(gemm_stack(s, "ctx.qkv", s->act_a, dm, 3, w3, o3, dm, R, st));
+                    }
+                    if (tc.qk_layernorm) LCM_TRY(qk_norm(s, "ctx.qk_norm", tc, L.sa, s->act_q, s->act_k, R, st));
                     ProfScope ps(&s->prof, "ctx.rope_store", 5.0 * R * dm * es, 0.0, st);
                     LCM_TRY(launch_rope_store(s->act_q, s->act_k, s->act_v, s->self_k + l * self_layer, s->self_v + l * self_layer,
                                               s->self_rows, s->pos_rows, s->rope_cos, s->rope_sin, R, dm, s->cap,

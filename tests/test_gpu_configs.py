@@ -175,6 +175,15 @@ def test_config2_base_lcm_1_6b_forward():
     d_stack = rms(sub_unstacked, sub)
     print(f"  2 x 128: rms stacked-vs-separate q/k/v products {d_stack:.4f} (floor {d_ee:.4f})")
     assert d_stack <= NOISE_RATIO * d_ee, (d_stack, d_ee)
+    # the stacked launch also rotates q / k and scatters k / v into the cache in its epilogue; with LCMHIP_FUSE_ROPE=0 the
+    # same products are followed by the separate rotation-and-scatter pass: same roundings in the same order, same bits
+    os.environ["LCMHIP_FUSE_ROPE"] = "0"
+    try:
+        full_unfused = fwd(slice(0, 32))
+    finally:
+        del os.environ["LCMHIP_FUSE_ROPE"]
+        model._session_pool.clear()
+    assert torch.equal(full_unfused, full)
     del model
 
 
