@@ -295,31 +295,37 @@ __global__ __launch_bounds__(256) void k_attention(AttnQ qa, const T* __restrict
 // ------------------------------------------------------------------------------------------------
 // Causal prefill with many queries per document (bf16): a matrix-core kernel.  One workgroup = 64
 // consecutive queries of one (document, head); wave w owns queries 16w .. 16w + 15.  Keys / values are
-// walked in tiles of 32: the K tile sits row-major in LDS, the V tile TRANSPOSED ([dim][key slot], written
-// with 2-byte stores while staging), so that both products run on v_mfma_f32_16x16x32_bf16 without any
-// cross-lane exchange in between:
+// staged 64 at a time, both tiles row-major in LDS (16-byte stores), and consumed in groups of 32; the next
+// tile's rows are requested from HBM before the current tile's products start.  Both products run on
+// v_mfma_f32_16x16x32_bf16 without any cross-lane exchange in between:
 //   S^T[key][query]   = K (A operand, 16 keys x 32 dims)      x Q^T (B operand, from registers)
 //   O^T[dim][query]  += V^T (A operand, 16 dims x 32 key slots) x P^T (B operand = the lane's own scores)
 // After the first product lane (query q = lane % 16, quad = lane / 16) holds the scores of keys
 // 4 quad .. 4 quad + 3 of both 16-key halves -- exactly the 8 "k slots" the second product wants from this
-// lane if key slot 8 g + e is defined as key 4 g + e (e < 4) or 16 + 4 g + e - 4 (e >= 4); the V tile is
-// stored in that slot order.  Softmax statistics are per query = per lane (replicated over the 4 quads).
+// lane if key slot 8 g + e is defined as key 4 g + e (e < 4) or 16 + 4 g + e - 4 (e >= 4).  The V^T operand in
+// that slot order is two transposed LDS reads (ds_read_b64_tr_b16: the 16 lanes of quad g read the block of keys
+// 4 g .. 4 g + 3 x 16 dims and each receives one dim's column) of the row-major tile: keys 4 g + .. and
+// 16 + 4 g + ...  Rows of 288 bytes put the 8 key rows that a 32-lane half touches on 8 disjoint bank groups.
+// Softmax statistics are per query = per lane (replicated over the 4 quads).
 // ------------------------------------------------------------------------------------------------
 using bf16x8_t = __attribute__((ext_vector_type(8))) __bf16;
 using u32x4_t = __attribute__((ext_vector_type(4))) uint32_t;
 using f32x4_t = __attribute__((ext_vector_type(4))) float;
 
-constexpr int kPfKeys = 32;
+constexpr int kPfKeys = 32;                        // keys of one pair of products (one softmax update)
+constexpr int kPfStage = 64;                       // keys staged per barrier pair: two such groups
 constexpr int kPfKRow = 256 + 16;                  // padded K row (bytes)
-constexpr int kPfVRow = 64 + 16;                   // padded V^T row: 32 key slots (bytes)
+constexpr int kPfVRow = 256 + 32;                  // padded V row (bytes)
+using s16x4_t = __attribute__((ext_vector_type(4))) short;
+using s16x8_t = __attribute__((ext_vector_type(8))) short;
 
 __global__ __launch_bounds__(256) void k_attention_prefill(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
                                                            const bf16_t* __restrict__ vc, const int32_t* __restrict__ slot_map,
                                                            bf16_t* __restrict__ out, int s, int n_heads, int cap, int base_keys,
                                                            KeyWindow win) {
-    __shared__ __attribute__((aligned(16))) char smem[kPfKeys * kPfKRow + kHeadDim * kPfVRow];
+    __shared__ __attribute__((aligned(16))) char smem[kPfStage * kPfKRow + kPfStage * kPfVRow];
     char* ks = smem;
-    char* vs = smem + kPfKeys * kPfKRow;
+    char* vs = smem + kPfStage * kPfKRow;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int qtiles = (s + 63) / 64;
     const int qt = blockIdx.x % qtiles;
@@ -359,30 +365,41 @@ __global__ __launch_bounds__(256) void k_attention_prefill(const bf16_t* __restr
     // staging: thread -> (key = tid / 16 (+16), 16-byte piece = tid % 16) of the 32 x 256-byte tiles
     const int skey = tid >> 4, spiece = tid & 15;
 
-    for (int k0 = 0; k0 < block_keys; k0 += kPfKeys) {
-        u32x4_t kreg[2], vreg[2];
+    constexpr int NH = kPfStage / 16;
+    u32x4_t kreg[NH], vreg[NH];
+    auto request_tile = [&](int k0) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NH; ++h) {
             int key = k0 + skey + 16 * h;
             key = key < block_keys ? key : block_keys - 1;
             kreg[h] = *reinterpret_cast<const u32x4_t*>(kc + hbase + (size_t)key * kHeadDim + spiece * 8);
             vreg[h] = *reinterpret_cast<const u32x4_t*>(vc + hbase + (size_t)key * kHeadDim + spiece * 8);
         }
-        __syncthreads();   // the previous tile is consumed
+    };
+    request_tile(0);
+    // transposed reads of the V tile: lane 4 q + p of quad g supplies the address of key row 4 g + q, dims 4 p .. 4 p + 3
+    // of the 16-dim block (+ 32 t bytes for block t, + 16 rows for the second half of the key slots)
+    const char* vtr0 = vs + (4 * quad + (qi >> 2)) * kPfVRow + 8 * (qi & 3);
+
+    for (int kt = 0; kt < block_keys; kt += kPfStage) {
+        // Raw barriers: __syncthreads() would also wait for the rows requested ahead.  The previous tile is consumed
+        // (its LDS reads have returned: the products that used them were issued) ...
+        asm volatile("s_barrier" ::: "memory");
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NH; ++h) {
             const int kk = skey + 16 * h;                                       // key inside the tile
             *reinterpret_cast<u32x4_t*>(ks + kk * kPfKRow + spiece * 16) = kreg[h];
-            const int vslot = (kk < 16) ? (kk >> 2) * 8 + (kk & 3) : ((kk - 16) >> 2) * 8 + 4 + ((kk - 16) & 3);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const uint32_t w = vreg[h][e];
-                *reinterpret_cast<uint16_t*>(vs + (spiece * 8 + 2 * e) * kPfVRow + vslot * 2) = (uint16_t)(w & 0xffffu);
-                *reinterpret_cast<uint16_t*>(vs + (spiece * 8 + 2 * e + 1) * kPfVRow + vslot * 2) = (uint16_t)(w >> 16);
-            }
+            *reinterpret_cast<u32x4_t*>(vs + kk * kPfVRow + spiece * 16) = vreg[h];
         }
-        __syncthreads();
-        if (k0 >= wave_keys) continue;   // wave-uniform: every key of the tile is masked for this wave's queries
+        if (kt + kPfStage < block_keys) request_tile(kt + kPfStage);   // in flight during this tile's products
+        // ... and this tile is visible once every wave's LDS stores have completed
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int sub = 0; sub < kPfStage / kPfKeys; ++sub) {
+        const int k0 = kt + sub * kPfKeys;
+        if (k0 >= wave_keys) break;      // wave-uniform: every further key of the tile is masked for this wave's queries
+        const char* ksub = ks + sub * kPfKeys * kPfKRow;
+        const char* vtr = vtr0 + sub * kPfKeys * kPfVRow;
 
         // ---- scores of the tile's two 16-key halves
         f32x4_t sc[2];
@@ -391,7 +408,7 @@ __global__ __launch_bounds__(256) void k_attention_prefill(const bf16_t* __restr
             sc[h] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
-                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(ks + (16 * h + qi) * kPfKRow + 64 * st + 16 * quad);
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(ksub + (16 * h + qi) * kPfKRow + 64 * st + 16 * quad);
                 sc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[st], sc[h], 0, 0, 0);
             }
         }
@@ -426,8 +443,12 @@ __global__ __launch_bounds__(256) void k_attention_prefill(const bf16_t* __restr
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             o[t] *= alpha;
-            const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vs + (16 * t + qi) * kPfVRow + 16 * quad);
+            typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4;
+            const s16x4_t v_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vtr + 32 * t));
+            const s16x4_t v_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vtr + 16 * kPfVRow + 32 * t));
+            const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(v_lo, v_hi, 0, 1, 2, 3, 4, 5, 6, 7));
             o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[t], 0, 0, 0);
+        }
         }
     }
     if (j < s) {

@@ -184,13 +184,15 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& p, const f32x4 (&ac
                         if ((p.rope_mask >> p.stack_sel) & 1) {
                             // the projection's output is rounded to the operand dtype first (as a separate rotation pass
                             // would read it), rotated in fp32, and rounded again by the store
-                            const int pos = p.rope_pos[m], pair0 = (n & 127) >> 1;
+                            const int pos = p.rope_pos[m], pair0 = (n & 127) >> 1;      // n is a multiple of 8
+                            const float4 c4 = *reinterpret_cast<const float4*>(p.rope_cos + pos * 64 + pair0);
+                            const float4 s4 = *reinterpret_cast<const float4*>(p.rope_sin + pos * 64 + pair0);
+                            const float cs[4] = {c4.x, c4.y, c4.z, c4.w}, sn[4] = {s4.x, s4.y, s4.z, s4.w};
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
-                                const float cs = p.rope_cos[pos * 64 + pair0 + j], sn = p.rope_sin[pos * 64 + pair0 + j];
                                 v[2 * j] = bf16_to_f32(f32_to_bf16(v[2 * j]));
                                 v[2 * j + 1] = bf16_to_f32(f32_to_bf16(v[2 * j + 1]));
-                                rope_rotate(v[2 * j], v[2 * j + 1], cs, sn);
+                                rope_rotate(v[2 * j], v[2 * j + 1], cs[j], sn[j]);
                             }
                         }
                     }
