@@ -142,3 +142,52 @@ def test_base_qk_layernorm_forward_and_generation():
     out_g, _ = run_hip_base(arch, sd, x[:, :4], nz, 4, opts, model=model)
     worst, cos = compare(out_g.hypotheses, ref_g, _norm_sd(sd), start=4)
     assert worst <= FP32_MAX_ABS and cos >= FP32_COS, (worst, cos)
+
+
+def test_fused_rotation_and_cache_scatter_ragged_rows():
+    """The q / k / v product of many rows rotates q / k and writes k / v into the cache in its epilogue.  7 x 300
+    positions (2100 rows: the last 128-row tile is ragged; 300 positions per document cross the 64-key stages of the
+    prefill attention) on a 2-layer, d = 1024 decoder in bf16: the same bits as with the separate
+    rotation-and-scatter pass (LCMHIP_FUSE_ROPE=0, read when a session is created), and the bf16 bar against the oracle."""
+    import os
+    from lcm.datasets.batch import EmbeddingsBatch
+    from lcm.models.base_lcm import BaseLCModelConfig, TransformerConfig, create_base_lcm_model
+    from oracle.weights import synthetic_prompts
+    cfg = oracle.get_base_arch("mini_base_lcm")
+    cfg.model_dim, cfg.lcm.num_heads, cfg.lcm.num_layers, cfg.lcm.ffn_inner_dim = 1024, 8, 2, 2048
+    sd = oracle.init_state_dict(cfg, seed=5, qk_gain=2.0, pos_std=0.5)
+    mc = BaseLCModelConfig(
+        model_dim=1024, max_seq_len=512, sonar_normalizer_name="dummy_sonar_normalizer",
+        lcm=TransformerConfig(num_layers=2, num_attn_heads=8, ffn_inner_dim=2048, use_swiglu=True,
+                              layer_normalization_style="rms", pos_embedding_style="rope", mha_output_proj_bias=True))
+    model = create_base_lcm_model(mc, device="cuda:0", dtype=torch.bfloat16)
+    assert set(model.state_dict()) == set(sd)
+    model.load_state_dict(sd)
+    x = synthetic_prompts(oracle.load_dummy_normalizer(), 7, 300, seed=99)
+    xb = x.cuda().bfloat16()
+
+    def fwd_and_kernels():
+        out = model.predict_next_sentence(EmbeddingsBatch(xb, None)).seqs
+        sess = model._session_pool[0]
+        sess.profile_enable(True)
+        model.predict_next_sentence(EmbeddingsBatch(xb, None))
+        names = {r["name"] for r in sess.profile() if r["launches"]}
+        sess.profile_enable(False)
+        return out, names
+
+    fused, names = fwd_and_kernels()
+    assert "ctx.qkv_rope" in names and "ctx.rope_store" not in names, names    # the fused launch is what ran
+    model._session_pool.clear()
+    os.environ["LCMHIP_FUSE_ROPE"] = "0"
+    try:
+        separate, names = fwd_and_kernels()
+    finally:
+        del os.environ["LCMHIP_FUSE_ROPE"]
+        model._session_pool.clear()
+    assert "ctx.rope_store" in names and "ctx.qkv_rope" not in names, names
+    assert torch.equal(fused, separate)
+    sd16 = {k: v.bfloat16().float() for k, v in sd.items()}
+    ref16 = oracle.OracleBaseLCM(cfg, sd16).predict(x.bfloat16().float())
+    c, s = sd16["frontend.sonar_normalizer.center"], sd16["frontend.sonar_normalizer.scale"]
+    cos = torch.nn.functional.cosine_similarity((fused.cpu().float() - c) / s, (ref16 - c) / s, dim=-1)
+    assert cos.min() >= BF16_COS, float(cos.min())
