@@ -319,7 +319,7 @@ constexpr int kPfVRow = 256 + 32;                  // padded V row (bytes)
 using s16x4_t = __attribute__((ext_vector_type(4))) short;
 using s16x8_t = __attribute__((ext_vector_type(8))) short;
 
-__global__ __launch_bounds__(256) void k_attention_prefill(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
+__global__ __launch_bounds__(256, 4) void k_attention_prefill(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
                                                            const bf16_t* __restrict__ vc, const int32_t* __restrict__ slot_map,
                                                            bf16_t* __restrict__ out, int s, int n_heads, int cap, int base_keys,
                                                            KeyWindow win) {
@@ -328,9 +328,13 @@ __global__ __launch_bounds__(256) void k_attention_prefill(const bf16_t* __restr
     char* vs = smem + kPfStage * kPfKRow;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int qtiles = (s + 63) / 64;
-    const int qt = blockIdx.x % qtiles;
-    const int head = (blockIdx.x / qtiles) % n_heads;
-    const int doc = blockIdx.x / (qtiles * n_heads);
+    // Workgroups are dealt to the 8 XCDs round-robin; the query tiles of one (document, head) walk the same keys, so
+    // consecutive tile ids are mapped onto ONE XCD (its L2 then serves the second walk).
+    int bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);
+    const int qt = bid % qtiles;
+    const int head = (bid / qtiles) % n_heads;
+    const int doc = bid / (qtiles * n_heads);
     const int slot = slot_map ? slot_map[doc] : doc;
     const int d = n_heads * kHeadDim;
     const int qi = lane & 15, quad = lane >> 4;
