@@ -327,6 +327,13 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_dma(GemmArgs p) {
     const int wn = wid & 1, wm = wid >> 1;           // 4 x 2 waves, 32 activation rows x 32 weight rows each
     const int m0 = blockIdx.z * BM;
     const uint32_t kbytes = (uint32_t)p.K * 2;
+#ifdef LCM_DMA_STAMPS
+    // timeline probe (scripts/gemm_dma_timeline.py): 100 MHz wall-clock stamps of workgroup (x, y) into the otherwise
+    // unused split-K workspace of an unsplit launch: start, first chunk landed, K loop done, epilogue done
+    uint64_t* const stamps = (EPI != EPI_PARTIAL && p.partial != nullptr)
+                                 ? reinterpret_cast<uint64_t*>(p.partial) + 4 * (size_t)(blockIdx.x + gridDim.x * blockIdx.z) : nullptr;
+    if (stamps && tid == 0) stamps[0] = __builtin_amdgcn_s_memrealtime();
+#endif
     const int nch512 = (int)(kbytes / kChunkBytes);
     const int cps = (nch512 + (int)gridDim.y - 1) / (int)gridDim.y;      // 512-byte chunks per split, as planned
     const int c_begin = 2 * blockIdx.y * cps, c_end = 2 * min(nch512, (int)(blockIdx.y + 1) * cps);   // in 256-byte chunks
@@ -407,6 +414,9 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_dma(GemmArgs p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
+#ifdef LCM_DMA_STAMPS
+        if (stamps && tid == 0 && c == 0) stamps[1] = __builtin_amdgcn_s_memrealtime();
+#endif
         const char* base = smem + (c % 3) * kDmaStage;
         const bool more = c + 2 < nc;
         const int nbuf = (c + 2) % 3;
@@ -468,8 +478,15 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_dma(GemmArgs p) {
                     acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ks][tn], x[ks][tm], acc[tn][tm], 0, 0, 0);
     }
 #endif
+#ifdef LCM_DMA_STAMPS
+    if (stamps && tid == 0) stamps[2] = __builtin_amdgcn_s_memrealtime();
+#endif
     gemm_epilogue<bf16_t, EPI, 2, 2>(p, acc, m0 + wm * 32, DUAL ? blockIdx.x * 32 + wn * 16 : blockIdx.x * 64 + wn * 32,
                                      blockIdx.y, lane);
+#ifdef LCM_DMA_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+    if (stamps && tid == 0) stamps[3] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 
