@@ -345,6 +345,32 @@ def test_attention(hip, dtype, causal, s, base):
     assert (out.float().cpu() - ref).abs().max() <= tol
 
 
+@pytest.mark.parametrize("n_docs,H,s,base", [(3, 4, 30, 0), (5, 4, 70, 3), (1, 12, 129, 64), (7, 16, 64, 63)])
+def test_attention_prefill_grid_shapes(hip, n_docs, H, s, base):
+    """The matrix-core prefill kernel over grids that are and are not a multiple of the 8 XCDs (its tile order is
+    remapped only in the first case), key ranges that end inside, at and just past a 64-key stage, one to three query
+    tiles per (document, head)."""
+    from oracle.model import sdpa
+    torch.manual_seed(n_docs + H + s)
+    dtype, cap = torch.bfloat16, 256
+    d = H * 128
+    kc = torch.randn(n_docs + 1, H, cap, 128).cuda().to(dtype)
+    vc = torch.randn(n_docs + 1, H, cap, 128).cuda().to(dtype)
+    slots = list(range(n_docs, 0, -1))
+    slot = torch.tensor(slots, dtype=torch.int32).cuda()
+    q = (2 * torch.randn(n_docs * s, d)).cuda().to(dtype)
+    out = torch.empty_like(q)
+    hip.check(hip.lib.lcmhip_attention(hip.ptr(q), hip.ptr(kc), hip.ptr(vc), hip.ptr(slot), hip.ptr(out), n_docs, s, H, cap,
+                                       base, 1, hip.dtype_code(dtype), _st(hip)))
+    nk = base + s
+    qh = q.float().cpu().view(n_docs, s, H, 128).transpose(1, 2)
+    kh = kc.float().cpu()[slots, :, :nk]
+    vh = vc.float().cpu()[slots, :, :nk]
+    mask = torch.full((nk, nk), float("-inf")).triu(1)[nk - s:]
+    ref = sdpa(qh, kh, vh, None, mask).transpose(1, 2).reshape(n_docs * s, d)
+    assert (out.float().cpu() - ref).abs().max() <= 2e-2
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("mode", ["plain", "extra_const", "dup_init", "bare"])
 @pytest.mark.parametrize("kind", ["rms", "standard"])
