@@ -799,11 +799,19 @@ __global__ __launch_bounds__(512) void k_gemm_big256x128(GemmArgs p) {
     const int w_off = 2 * kHT + (wc * 64 + frow) * kRowB;                   // + 16 tn rows
     const int slot0 = (((lane >> 4)) ^ fsw) * 16, slot1 = ((4 + (lane >> 4)) ^ fsw) * 16;
 
+#ifdef LCM_DMA_STAMPS
+    // timeline probe (see k_gemm_dma): start, first K tile landed, K loop done, epilogue done, per workgroup
+    uint64_t* const stamps = p.partial != nullptr ? reinterpret_cast<uint64_t*>(p.partial) + 4 * (size_t)blockIdx.x : nullptr;
+    if (stamps && tid == 0) stamps[0] = __builtin_amdgcn_s_memrealtime();
+#endif
     // prologue: K tile 0 whole; of K tile 1 the weight half and activation half 0 (nk >= 4)
     stage_w(0, 0); stage_x(0, 0, 0); stage_x(1, 0, 0);
     stage_w(1, 1); stage_x(0, 1, 1);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#ifdef LCM_DMA_STAMPS
+    if (stamps && tid == 0) stamps[1] = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // Fragment reads are issued by hand (ds_read_b128 through inline asm) and retired with COUNTED lgkmcnt waits: the
     // compiler's own waits drain every pending LDS read before a product, which leaves a read only the few products
@@ -904,7 +912,14 @@ __global__ __launch_bounds__(512) void k_gemm_big256x128(GemmArgs p) {
     const int m_wave0 = m0 + wr * 64, n_wave0 = bx * 128 + wc * 64;
     float4 res0[big_resid_rounds<EPI, NC>()];
     big_load_resid<EPI, NC>(p, m_wave0, n_wave0, 0, lane, res0);
+#ifdef LCM_DMA_STAMPS
+    if (stamps && tid == 0) stamps[2] = __builtin_amdgcn_s_memrealtime();
+#endif
     big_epilogue<bf16_t, EPI, 4>(p, acc, smem, wid, m_wave0, n_wave0, 0, lane, res0);
+#ifdef LCM_DMA_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+    if (stamps && tid == 0) stamps[3] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // K splits for the split-K (slab) form: two workgroups per CU (512; with one per CU a workgroup's four waves have
