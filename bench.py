@@ -49,15 +49,37 @@ def parse():
     ap.add_argument("--cpu-sentence-steps", type=int, default=3,
                     help="generated sentences per document the CPU baseline runs after its prefill")
     ap.add_argument("--no-check", action="store_true", help="skip the cross-check of the timed output")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="launch the sampling loop kernel by kernel instead of replaying it from a HIP graph (profiler counter passes)")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="ranks only rendezvous over gloo on the CPU and report the world size (no GPU work)")
     return ap.parse_args()
 
 
+def visible_gpu_count():
+    """GPUs this process tree may use, from the environment and the kernel driver's topology files only: the parent
+    of the ranks must not load the GPU runtime.  None when it cannot be told."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip()])
+    import glob
+    n, seen = 0, False
+    for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            with open(path) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+        except OSError:
+            continue
+        seen = True
+        n += int(props.get("simd_count", "0")) > 0          # CPU nodes have no SIMDs
+    return n if seen else None
+
+
 def launch_ranks(args):
     """`--gpus N` without a launcher around it: start N ranks as ONE child (`python -m torch.distributed.run`)
-    and leave with its exit code.  This parent never touches the GPU, so nothing that has initialised the GPU is
-    ever replaced or forked.  Under a launcher (WORLD_SIZE set) the world size must equal --gpus."""
+    and leave with its exit code.  This parent never calls into the GPU runtime (the device count comes from the
+    environment or the driver's topology files), so nothing that has initialised the GPU is ever replaced or forked.  Under a launcher (WORLD_SIZE set) the world size must equal --gpus."""
     world_env = os.environ.get("WORLD_SIZE")
     if world_env is not None:
         if int(world_env) != args.gpus:
@@ -69,8 +91,8 @@ def launch_ranks(args):
     import socket
     import subprocess
     if not args.launcher_selftest and not os.environ.get("LCM_BENCH_ONE_DEVICE"):
-        n_dev = torch.cuda.device_count()        # counting devices does not initialise the GPU
-        if n_dev < args.gpus:
+        n_dev = visible_gpu_count()               # standard library only: nothing here touches the GPU runtime
+        if n_dev is not None and n_dev < args.gpus:
             print(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) are visible", file=sys.stderr)
             sys.exit(2)
     with socket.socket() as sock:
@@ -358,6 +380,9 @@ def main():
     model.init_parameters(seed=0, modulator_std=0.2)       # non-zero adaLN modulators: every layer does real work
     normalizer = load_model_from_card("dummy_sonar_normalizer", device=device, dtype=torch.bfloat16)
     model.sonar_normalizer.load_state_dict(normalizer.state_dict())
+    if args.no_graph:
+        from lcm import _hip
+        model.session_flags = _hip.SESSION_NO_GRAPH
     gen = TwoTowerDiffusionLCMGenerator(model, DiffusionLCMGeneratorOptions(**opts))
 
     first_doc = rank * B
@@ -375,9 +400,9 @@ def main():
             lens = torch.tensor([h[0].seq.shape[0] for h in out.hypotheses], device=device, dtype=torch.int32)
             if distributed:
                 if backend == "nccl":
-                    seqs, lens = all_gather_generations(seqs, lens)
+                    seqs, lens = all_gather_generations(seqs, lens, width=B)
                 else:
-                    seqs, lens = all_gather_generations(seqs.cpu(), lens.cpu())
+                    seqs, lens = all_gather_generations(seqs.cpu(), lens.cpu(), width=B)
                     seqs, lens = seqs.to(device), lens.to(device)
         return seqs, lens
 

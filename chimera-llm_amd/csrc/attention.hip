@@ -386,9 +386,10 @@ __global__ __launch_bounds__(256, 4) void k_attention_prefill(const bf16_t* __re
     const char* vtr0 = vs + (4 * quad + (qi >> 2)) * kPfVRow + 8 * (qi & 3);
 
     for (int kt = 0; kt < block_keys; kt += kPfStage) {
-        // Raw barriers: __syncthreads() would also wait for the rows requested ahead.  The previous tile is consumed
-        // (its LDS reads have returned: the products that used them were issued) ...
-        asm volatile("s_barrier" ::: "memory");
+        // Raw barriers: __syncthreads() would also wait for the rows requested ahead.  The previous tile is consumed:
+        // the wait retires this wave's LDS reads of it (only LDS operations count here, the global rows requested
+        // ahead stay in flight), so no other wave's stores of the next tile can overtake a read still pending ...
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
             const int kk = skey + 16 * h;                                       // key inside the tile

@@ -212,6 +212,8 @@ struct GemmArgs {
 bool gemm_stack_is_fused(const GemmArgs& a);
 // C = A W^T with the epilogue applied (split-K + finishing pass when a.partial is given and it pays).
 int launch_gemm(const GemmArgs& a, hipStream_t st);
+// Resolves the current device's copy of the static scratch array of lcmhip_gemm_static (noalloc.hip), once per device.
+int static_scratch_init();
 // Raw partial products only: slab [*splits][M][N] in a.partial, to be summed by the consumer.
 int launch_gemm_partial(const GemmArgs& a, int* splits, hipStream_t st);
 

@@ -33,9 +33,18 @@ static int scratch_for_current_device(void** out) {
     return LCMHIP_OK;
 }
 
+// Called by lcmhip_model_create / lcmhip_session_create (and lcmhip_static_init): the first resolution on a device
+// loads this file's code object and places the array, which must not happen inside a stream capture.
+int static_scratch_init() {
+    void* p = nullptr;
+    return scratch_for_current_device(&p);
+}
+
 }  // namespace lcmhip
 
 using namespace lcmhip;
+
+extern "C" int lcmhip_static_init(void) { return static_scratch_init(); }
 
 extern "C" int lcmhip_gemm_static(const void* A, int32_t lda, const void* W, const void* W2, const void* bias,
                                   const void* bias2, const float* gate, void* out, int32_t ldo, int32_t M, int32_t N,

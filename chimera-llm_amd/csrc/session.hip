@@ -201,8 +201,9 @@ struct lcmhip_session {
     int max_batch = 0, cap = 0, max_steps = 0, rows_cap = 0, chunk_rows = 0;
     bool keep_context = false;
     char* init_bias_pos = nullptr;  // initial_proj bias + position 0 of the denoiser's learned positions (operand dtype)
-    bool stack_products = true;     // q / k / v (and cross k / v) of many rows in one launch; LCMHIP_STACK=0 turns it off
-    bool fuse_rope_store = true;    // ... with the rotation and the cache scatter in its epilogue; LCMHIP_FUSE_ROPE=0 turns it off
+    bool stack_products = true;     // q / k / v (and cross k / v) of many rows in one launch; off with LCMHIP_SESSION_SEPARATE_QKV
+    bool fuse_rope_store = true;    // ... with the rotation and the cache scatter in its epilogue; off with LCMHIP_SESSION_SEPARATE_ROPE
+    bool use_graphs = true;         // the sampling loop is replayed from a HIP graph; off with LCMHIP_SESSION_NO_GRAPH
     // carved device buffers
     int32_t *slot_map = nullptr, *pos_rows = nullptr, *self_rows = nullptr, *cross_rows = nullptr, *slot0_rows = nullptr;
     char *self_k = nullptr, *self_v = nullptr, *cross_k = nullptr, *cross_v = nullptr;
@@ -244,11 +245,6 @@ struct Carver {
         return p;
     }
 };
-
-static bool env_flag(const char* name) {
-    const char* v = getenv(name);
-    return v && v[0] && v[0] != '0';
-}
 
 // Lays out the workspace; with base == nullptr only measures it.
 static size_t carve(lcmhip_session* s, char* base) {
@@ -597,7 +593,7 @@ using namespace lcmhip;
 extern "C" {
 
 const char* lcmhip_last_error(void) { return g_last_error.c_str(); }
-int lcmhip_version(void) { return 100; }
+int lcmhip_version(void) { return LCMHIP_ABI_VERSION; }
 
 int lcmhip_model_create(const lcmhip_model_desc* desc, lcmhip_model** out) {
     LCM_REQUIRE(desc && out, "model_create: null argument");
@@ -613,6 +609,13 @@ int lcmhip_model_create(const lcmhip_model_desc* desc, lcmhip_model** out) {
             return fail(LCMHIP_ERR_UNSUPPORTED, "denoiser: only learned positions (or none) are implemented for the latents");
     }
     LCM_REQUIRE(desc->embed_scale >= 0.f, "model_create: embed_scale");
+    {
+        // the library's set-up call: resolves the static scratch of lcmhip_gemm_static on the current device (a model
+        // table can also be built and validated on a host without a GPU: nothing to resolve there)
+        int n_dev = 0;
+        if (hipGetDeviceCount(&n_dev) == hipSuccess && n_dev > 0) LCM_TRY(static_scratch_init());
+        else (void)hipGetLastError();
+    }
     auto* m = new lcmhip_model();
     m->desc = *desc;
     m->base = base;
@@ -715,7 +718,10 @@ int lcmhip_model_destroy(lcmhip_model* m) {
 }
 
 // ------------------------------------------------------------------------------------------------ session life cycle
-static int session_dims(lcmhip_session* s, const lcmhip_model* m, int max_batch, int max_ctx, int max_steps) {
+static int session_dims(lcmhip_session* s, const lcmhip_model* m, int max_batch, int max_ctx, int max_steps, uint32_t flags) {
+    constexpr uint32_t known = LCMHIP_SESSION_KEEP_CONTEXT | LCMHIP_SESSION_SEPARATE_QKV | LCMHIP_SESSION_SEPARATE_ROPE |
+                               LCMHIP_SESSION_NO_GRAPH;
+    LCM_REQUIRE((flags & ~known) == 0, "session: unknown flag bits");
     LCM_REQUIRE(m && m->finalized, "session: model is not finalized");
     LCM_REQUIRE(max_batch >= 1 && max_batch <= 65536, "session: max_batch");
     LCM_REQUIRE(max_ctx >= 1 && max_ctx <= m->desc.max_seq_len, "session: max_ctx exceeds the model's max_seq_len");
@@ -728,31 +734,29 @@ static int session_dims(lcmhip_session* s, const lcmhip_model* m, int max_batch,
     // rows of one contextualizer pass: large enough for matrix-core-bound GEMMs when a prompt is long
     s->chunk_rows = std::max(2 * max_batch, (int)std::min<int64_t>(4096, std::max<int64_t>(512, (int64_t)max_batch * max_ctx)));
     s->rows_cap = std::max(s->chunk_rows, max_steps);
-    s->keep_context = env_flag("LCMHIP_KEEP_CONTEXT");
-    {
-        const char* e = getenv("LCMHIP_STACK");
-        s->stack_products = !(e && e[0] == '0');
-        e = getenv("LCMHIP_FUSE_ROPE");
-        s->fuse_rope_store = !(e && e[0] == '0');
-    }
+    s->keep_context = (flags & LCMHIP_SESSION_KEEP_CONTEXT) != 0;
+    s->stack_products = (flags & LCMHIP_SESSION_SEPARATE_QKV) == 0;
+    s->fuse_rope_store = (flags & LCMHIP_SESSION_SEPARATE_ROPE) == 0;
+    s->use_graphs = (flags & LCMHIP_SESSION_NO_GRAPH) == 0;
     return LCMHIP_OK;
 }
 
 int lcmhip_session_workspace_bytes(const lcmhip_model* m, int32_t max_batch, int32_t max_ctx, int32_t max_steps,
-                                   size_t* bytes) {
+                                   uint32_t flags, size_t* bytes) {
     LCM_REQUIRE(bytes, "workspace_bytes: null output");
     lcmhip_session tmp;
-    LCM_TRY(session_dims(&tmp, m, max_batch, max_ctx, max_steps));
+    LCM_TRY(session_dims(&tmp, m, max_batch, max_ctx, max_steps, flags));
     *bytes = carve(&tmp, nullptr);
     return LCMHIP_OK;
 }
 
-int lcmhip_session_create(lcmhip_model* m, int32_t max_batch, int32_t max_ctx, int32_t max_steps, void* workspace,
-                          size_t bytes, lcmhip_session** out) {
+int lcmhip_session_create(lcmhip_model* m, int32_t max_batch, int32_t max_ctx, int32_t max_steps, uint32_t flags,
+                          void* workspace, size_t bytes, lcmhip_session** out) {
     LCM_REQUIRE(out && workspace, "session_create: null argument");
     LCM_REQUIRE(((uintptr_t)workspace % 256) == 0, "session_create: workspace must be 256-byte aligned");
+    LCM_TRY(static_scratch_init());     // never inside a capture: see lcmhip_gemm_static
     auto s = std::make_unique<lcmhip_session>();
-    LCM_TRY(session_dims(s.get(), m, max_batch, max_ctx, max_steps));
+    LCM_TRY(session_dims(s.get(), m, max_batch, max_ctx, max_steps, flags));
     const size_t need = carve(s.get(), static_cast<char*>(workspace));
     LCM_REQUIRE(bytes >= need, "session_create: workspace too small");
     {
@@ -1085,7 +1089,7 @@ int lcmhip_base_forward(lcmhip_session* s, const float* x, int32_t n_tokens, int
 
 int lcmhip_session_read_context(lcmhip_session* s, int32_t row, float* out, void* stream) {
     LCM_REQUIRE(s && out, "read_context: null argument");
-    if (!s->keep_context) return fail(LCMHIP_ERR_STATE, "read_context: session was created without LCMHIP_KEEP_CONTEXT=1");
+    if (!s->keep_context) return fail(LCMHIP_ERR_STATE, "read_context: session was created without LCMHIP_SESSION_KEEP_CONTEXT");
     LCM_REQUIRE(row >= 0 && row < s->n_active, "read_context: row out of range");
     const size_t dm = s->model->desc.model_dim;
     LCM_HIP_CHECK(hipMemcpyAsync(out, s->kept_ctx + (size_t)s->h_slot[row] * s->cap * dm, (size_t)s->ctx_len * dm * 4,
@@ -1197,22 +1201,16 @@ static int denoise_impl(lcmhip_session* s, const float* noise, const float* vari
     // Graph replay: the loop is ~6000 launches per sentence whose arguments depend only on the schedule and on
     // the number of active documents, so it is recorded once per session and replayed.  Needs a non-default
     // stream (capture is not defined on the legacy stream); per-launch profiling and latent traces run eagerly.
-    const char* genv = getenv("LCMHIP_GRAPH");   // read per call: tests switch it within one process
-    const bool graphs_on = !genv || atoi(genv) != 0;
-    if (!graphs_on || st == nullptr || s->prof.enabled || latents_trace != nullptr)
+    if (!s->use_graphs || st == nullptr || s->prof.enabled || latents_trace != nullptr)
         return denoise_body(s, noise, out, latents_trace, st, nullptr);
     const size_t io_bytes = (size_t)s->n_active * s->model->desc.sonar_dim * 4;
-    const bool dbg = env_flag("LCMHIP_DEBUG_GRAPH");   // one stderr line per graph API call (diagnosing profiler stalls)
-#define LCM_GRAPH_DBG(what) do { if (dbg) { fprintf(stderr, "[lcmhip graph] %s (active %d)\n", what, s->n_active); fflush(stderr); } } while (0)
     auto it = s->graphs.find(s->n_active);
     if (it == s->graphs.end()) {
         if (s->graphs.size() >= 16) drop_graphs(s);   // documents finishing one by one: keep the cache bounded
         hipGraph_t graph = nullptr;
-        LCM_GRAPH_DBG("begin capture");
         LCM_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         const int rc = denoise_body(s, s->noise_buf, s->out_buf, nullptr, st, s->d_cross_keys);
         const hipError_t end = hipStreamEndCapture(st, &graph);
-        LCM_GRAPH_DBG("end capture");
         if (rc != LCMHIP_OK) {
             if (graph) (void)hipGraphDestroy(graph);
             return rc;
@@ -1220,21 +1218,13 @@ static int denoise_impl(lcmhip_session* s, const float* noise, const float* vari
         LCM_HIP_CHECK(end);
         hipGraphExec_t exec = nullptr;
         const hipError_t inst = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-        LCM_GRAPH_DBG("instantiated");
         (void)hipGraphDestroy(graph);
         LCM_HIP_CHECK(inst);
         it = s->graphs.emplace(s->n_active, exec).first;
     }
     LCM_HIP_CHECK(hipMemcpyAsync(s->noise_buf, noise, io_bytes, hipMemcpyDeviceToDevice, st));
-    LCM_GRAPH_DBG("launch");
     LCM_HIP_CHECK(hipGraphLaunch(it->second, st));
-    LCM_GRAPH_DBG("launched");
     LCM_HIP_CHECK(hipMemcpyAsync(out, s->out_buf, io_bytes, hipMemcpyDeviceToDevice, st));
-    if (dbg) {
-        LCM_HIP_CHECK(hipStreamSynchronize(st));
-        LCM_GRAPH_DBG("replay finished");
-    }
-#undef LCM_GRAPH_DBG
     return LCMHIP_OK;
 }
 

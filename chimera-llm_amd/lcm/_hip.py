@@ -21,6 +21,9 @@ POS_NONE, POS_LEARNED, POS_ROPE = 0, 1, 2
 PRED = {"sample": 0, "epsilon": 1, "v_prediction": 2}
 EPI_STORE, EPI_STORE_F32, EPI_RELU, EPI_SWIGLU, EPI_RESID = 0, 1, 2, 3, 4
 STATIC_SCRATCH_BYTES = 16 << 20      # LCMHIP_STATIC_SCRATCH_BYTES of include/lcmhip.h
+ABI_VERSION = 300                    # LCMHIP_ABI_VERSION of include/lcmhip.h: the layouts and signatures bound below
+# LCMHIP_SESSION_* flags of lcmhip_session_workspace_bytes / lcmhip_session_create
+SESSION_KEEP_CONTEXT, SESSION_SEPARATE_QKV, SESSION_SEPARATE_ROPE, SESSION_NO_GRAPH = 1, 2, 4, 8
 
 EXPORTS = [
     "lcmhip_last_error", "lcmhip_version",
@@ -30,7 +33,7 @@ EXPORTS = [
     "lcmhip_denoise_positions",
     "lcmhip_session_reorder", "lcmhip_session_context_len", "lcmhip_session_num_active",
     "lcmhip_session_read_context", "lcmhip_session_profile_enable", "lcmhip_session_profile",
-    "lcmhip_normalize", "lcmhip_denormalize", "lcmhip_norm_modulate", "lcmhip_gemm", "lcmhip_gemm_static", "lcmhip_gemm_partial",
+    "lcmhip_normalize", "lcmhip_denormalize", "lcmhip_norm_modulate", "lcmhip_gemm", "lcmhip_static_init", "lcmhip_gemm_static", "lcmhip_gemm_partial",
     "lcmhip_residual_norm",
     "lcmhip_ddim_cfg_step", "lcmhip_attention", "lcmhip_finalize_step", "lcmhip_stream_copy",
 ]
@@ -70,13 +73,16 @@ def _load() -> C.CDLL:
     lib.lcmhip_last_error.restype = C.c_char_p
     lib.lcmhip_last_error.argtypes = []
     lib.lcmhip_version.restype = C.c_int
+    lib.lcmhip_version.argtypes = []
+    if lib.lcmhip_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} implements lcmhip ABI {lib.lcmhip_version()}, this package binds ABI {ABI_VERSION}: rebuild it")
     sig = {
         "lcmhip_model_create": [C.POINTER(ModelDesc), C.POINTER(vp)],
         "lcmhip_model_bind_weight": [vp, C.c_char_p, vp, i32, i32, C.POINTER(i64)],
         "lcmhip_model_finalize": [vp],
         "lcmhip_model_destroy": [vp],
-        "lcmhip_session_workspace_bytes": [vp, i32, i32, i32, C.POINTER(C.c_size_t)],
-        "lcmhip_session_create": [vp, i32, i32, i32, vp, C.c_size_t, C.POINTER(vp)],
+        "lcmhip_session_workspace_bytes": [vp, i32, i32, i32, C.c_uint32, C.POINTER(C.c_size_t)],
+        "lcmhip_session_create": [vp, i32, i32, i32, C.c_uint32, vp, C.c_size_t, C.POINTER(vp)],
         "lcmhip_session_destroy": [vp],
         "lcmhip_session_set_schedule": [vp, C.POINTER(i32), i32, C.POINTER(f32), i32, f32, i32,
                                         C.POINTER(DenoiseParams), vp],
@@ -96,6 +102,7 @@ def _load() -> C.CDLL:
         "lcmhip_denormalize": [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp],
         "lcmhip_norm_modulate": [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp],
         "lcmhip_gemm": [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, C.c_size_t, vp],
+        "lcmhip_static_init": [],
         "lcmhip_gemm_static": [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
         "lcmhip_gemm_partial": [vp, i32, vp, vp, C.c_size_t, C.POINTER(i32), i32, i32, i32, i32, vp],
         "lcmhip_residual_norm": [vp, vp, i32, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],

@@ -155,6 +155,7 @@ class BaseLCModel(AbstractLCModel):
         self._handle = C.c_void_p()
         self._bind()
         self._session_pool: List[DeviceSession] = []
+        self.session_flags = 0     # _hip.SESSION_* bits given to every session this model creates (tests, profiling)
 
     # ---- parameters ---------------------------------------------------------------------------------
     def init_parameters(self, seed: int = 0, matrix_std: float = 0.02) -> None:
@@ -218,7 +219,7 @@ class BaseLCModel(AbstractLCModel):
     # ---- sessions -----------------------------------------------------------------------------------
     def acquire_session(self, max_batch: int, max_ctx: int) -> DeviceSession:
         for i, s in enumerate(self._session_pool):
-            if s.dims[0] >= max_batch and s.dims[1] >= max_ctx:
+            if s.dims[0] >= max_batch and s.dims[1] >= max_ctx and s.flags == int(self.session_flags):
                 return self._session_pool.pop(i)
         self._session_pool.clear()
         return DeviceSession(self, max_batch, max_ctx, 1)

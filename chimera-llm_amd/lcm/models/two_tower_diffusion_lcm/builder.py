@@ -176,26 +176,16 @@ class DeviceSession:
                  keep_context: bool = False) -> None:
         self.model = model
         self.dims = (max_batch, max_ctx, max_steps)
-        # the library sizes and carves the fp32 copy of the contextualizer output only when LCMHIP_KEEP_CONTEXT is
-        # set while the session is created (tests set it globally; encode() without a state bag needs it per session)
-        import os
-        saved = os.environ.get("LCMHIP_KEEP_CONTEXT")
-        if keep_context:
-            os.environ["LCMHIP_KEEP_CONTEXT"] = "1"
-        try:
-            nbytes = C.c_size_t(0)
-            _hip.check(_hip.lib.lcmhip_session_workspace_bytes(model._handle, max_batch, max_ctx, max_steps, C.byref(nbytes)))
-            self.workspace = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=model.device)
-            base = (self.workspace.data_ptr() + 255) // 256 * 256
-            self._h = C.c_void_p()
-            _hip.check(_hip.lib.lcmhip_session_create(model._handle, max_batch, max_ctx, max_steps, C.c_void_p(base),
-                                                      nbytes.value, C.byref(self._h)))
-        finally:
-            if keep_context:
-                if saved is None:
-                    del os.environ["LCMHIP_KEEP_CONTEXT"]
-                else:
-                    os.environ["LCMHIP_KEEP_CONTEXT"] = saved
+        # options of the session (lcmhip.h LCMHIP_SESSION_*): the model's, plus the fp32 copy of the contextualizer
+        # output that encode() without a state bag reads back
+        self.flags = int(getattr(model, "session_flags", 0)) | (_hip.SESSION_KEEP_CONTEXT if keep_context else 0)
+        nbytes = C.c_size_t(0)
+        _hip.check(_hip.lib.lcmhip_session_workspace_bytes(model._handle, max_batch, max_ctx, max_steps, self.flags, C.byref(nbytes)))
+        self.workspace = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=model.device)
+        base = (self.workspace.data_ptr() + 255) // 256 * 256
+        self._h = C.c_void_p()
+        _hip.check(_hip.lib.lcmhip_session_create(model._handle, max_batch, max_ctx, max_steps, self.flags, C.c_void_p(base),
+                                                  nbytes.value, C.byref(self._h)))
         self.schedule_key = None
 
     def __del__(self) -> None:
@@ -343,7 +333,7 @@ class DeviceSession:
 class DeviceContext:
     """Handle of the contextualizer output kept on the device (what the reference passes around as
     the `context` EmbeddingsBatch).  `seqs` reads it back when the session keeps a copy
-    (LCMHIP_KEEP_CONTEXT=1)."""
+    (`session_flags` with SESSION_KEEP_CONTEXT)."""
 
     def __init__(self, session: Optional[DeviceSession], length: int) -> None:
         self.session = session
@@ -399,6 +389,7 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
         self._bind()
         self._refresh_derived()
         self._session_pool: List[DeviceSession] = []
+        self.session_flags = 0     # _hip.SESSION_* bits given to every session this model creates (tests, profiling)
 
     # ---- parameters ---------------------------------------------------------------------------------
     def init_parameters(self, seed: int = 0, matrix_std: float = 0.02, modulator_std: float = 0.0) -> None:
@@ -538,7 +529,7 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
         else:
             steps = len(timesteps)
         for i, s in enumerate(self._session_pool):
-            if s.dims[0] >= max_batch and s.dims[1] >= max_ctx and s.dims[2] >= steps:
+            if s.dims[0] >= max_batch and s.dims[1] >= max_ctx and s.dims[2] >= steps and s.flags == int(self.session_flags):
                 sess = self._session_pool.pop(i)
                 break
         else:

@@ -27,6 +27,12 @@
 extern "C" {
 #endif
 
+/* Version of this ABI (struct layouts and signatures).  lcmhip_version() returns the value the library was built
+ * with; a caller built against another value must not bind.  200 -> 300: lcmhip_session_workspace_bytes and
+ * lcmhip_session_create take `flags`, lcmhip_static_init added; 100 -> 200: lcmhip_tower_desc.qk_layernorm,
+ * thresholding fields of lcmhip_denoise_params, variance_noise of lcmhip_ddim_cfg_step. */
+#define LCMHIP_ABI_VERSION 300
+
 #define LCMHIP_OK 0
 #define LCMHIP_ERR_INVALID (-1)     /* bad argument / shape the kernels do not support */
 #define LCMHIP_ERR_HIP (-2)         /* a HIP runtime call failed */
@@ -132,15 +138,22 @@ int lcmhip_model_destroy(lcmhip_model* m);
 
 /* ---- session: caches + scratch for one batch of documents --------------------------------- */
 
+/* Options of a session (`flags` of the two calls below; both calls of one session must get the same value). */
+#define LCMHIP_SESSION_KEEP_CONTEXT 1u  /* keep an fp32 copy of the contextualizer output for lcmhip_session_read_context */
+#define LCMHIP_SESSION_SEPARATE_QKV 2u  /* q / k / v products of many rows as three launches, not one stacked launch */
+#define LCMHIP_SESSION_SEPARATE_ROPE 4u /* rotation of q / k and the cache scatter as a pass of their own, not in the
+                                           stacked product's epilogue (same roundings: same bits) */
+#define LCMHIP_SESSION_NO_GRAPH 8u      /* the sampling loop is launched kernel by kernel, never replayed from a HIP graph */
+
 int lcmhip_session_workspace_bytes(const lcmhip_model* m, int32_t max_batch, int32_t max_ctx,
-                                   int32_t max_steps, size_t* bytes);
+                                   int32_t max_steps, uint32_t flags, size_t* bytes);
 
 /* `workspace` (device, 256-byte aligned, `bytes` long) holds the contextualizer KV cache
  * (lcm/nn/incremental_state.py:14-43), the per-layer cross-attention K/V of the context, the
  * adaLN modulation table and all activations.  Replaces the LCMIncrementalStateBag pair of
  * generator.py:172-181. */
 int lcmhip_session_create(lcmhip_model* m, int32_t max_batch, int32_t max_ctx, int32_t max_steps,
-                          void* workspace, size_t bytes, lcmhip_session** out);
+                          uint32_t flags, void* workspace, size_t bytes, lcmhip_session** out);
 int lcmhip_session_destroy(lcmhip_session* s);
 
 /* Replaces TwoTowerDiffusionLCModel.prep_for_denoising (builder.py:215-242) together with the
@@ -223,7 +236,7 @@ int lcmhip_session_num_active(const lcmhip_session* s);
 
 /* Copies the contextualizer output of active row `row`, positions [0, context_len), as fp32
  * (context_len, model_dim) into `out` (device).  Only kept when the session was created with
- * LCMHIP_KEEP_CONTEXT=1 in the environment (tests); otherwise returns LCMHIP_ERR_STATE. */
+ * LCMHIP_SESSION_KEEP_CONTEXT; otherwise returns LCMHIP_ERR_STATE. */
 int lcmhip_session_read_context(lcmhip_session* s, int32_t row, float* out, void* stream);
 
 /* Per-kernel timing with HIP events on `stream`, for roofline accounting.  While enabled, every
@@ -273,9 +286,14 @@ int lcmhip_gemm(const void* A, int32_t lda, const void* W, const void* W2, const
  * LCMHIP_STATIC_MAX_OUTPUTS (two fp32 partial tiles must fit), otherwise LCMHIP_ERR_INVALID.  All calls on one
  * GPU share that GPU's array: calls that overlap on one GPU (different streams or threads) race; calls on one
  * stream are ordered.  Nothing in the array has to be zero: every element a call reads it has written first.
- * Results equal lcmhip_gemm's with a workspace of LCMHIP_STATIC_SCRATCH_BYTES bit for bit. */
+ * Results equal lcmhip_gemm's with a workspace of LCMHIP_STATIC_SCRATCH_BYTES bit for bit.
+ * The array's address on a GPU is resolved once per GPU, which loads its code object and places the array: that
+ * first resolution must happen OUTSIDE any stream capture.  lcmhip_static_init() does it for the current device
+ * (lcmhip_model_create and lcmhip_session_create call it too); a lcmhip_gemm_static call on a device that has seen
+ * none of them resolves it itself and so must not be the first thing inside a capture. */
 #define LCMHIP_STATIC_SCRATCH_BYTES (16u << 20)
 #define LCMHIP_STATIC_MAX_OUTPUTS (LCMHIP_STATIC_SCRATCH_BYTES / 8u)
+int lcmhip_static_init(void);
 int lcmhip_gemm_static(const void* A, int32_t lda, const void* W, const void* W2, const void* bias,
                        const void* bias2, const float* gate, void* out, int32_t ldo, int32_t M, int32_t N,
                        int32_t K, int32_t epilogue, int32_t dtype, void* stream);

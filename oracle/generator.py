@@ -164,9 +164,10 @@ class OracleGenerator:
 
 
 class OracleScorer(OracleGenerator):
-    """Teacher-forced scoring, lcm/inference/two_tower_diffusion_lcm/scorer.py:27-314: at every step the model sees
-    the gold previous sentence, the prediction is recorded (never fed back), and a document leaves the batch after
-    its last sentence."""
+    """Teacher-forced scoring, lcm/inference/two_tower_diffusion_lcm/scorer.py:27-314 and, for a base LCM,
+    lcm/inference/lcm/scorer.py:19-198 (the same loop on the base generator's prefill / decode, lcm/generator.py:226-286):
+    at every step the model sees the gold previous sentence, the prediction is recorded (never fed back), and a
+    document leaves the batch after its last sentence."""
 
     @torch.inference_mode()
     def __call__(self, seqs_in: Tensor, text_lens: Optional[Tensor] = None, max_gen_len: Optional[int] = None,
@@ -187,17 +188,25 @@ class OracleScorer(OracleGenerator):
         sample_idx = torch.arange(B)
         hyps: List[List[Hyp]] = [[] for _ in range(B)]
         prefill_len = min_context_len - 1                                             # scorer.py:163-199
+        base = isinstance(model, OracleBaseLCM)
+        context = None if base else torch.empty(B, 0, model.model_dim)
         if prefill_len > 0:
-            context = model.encode(model.normalize(seqs[:, :prefill_len]), cache)
+            if base:
+                model.predict(seqs[:, :prefill_len], cache)                           # lcm/generator.py:226-246
+            else:
+                context = model.encode(model.normalize(seqs[:, :prefill_len]), cache)
             cache.increment_step_nr(prefill_len)
-        else:
-            context = torch.empty(B, 0, model.model_dim)
         for step_nr in range(min_context_len, T):
             n_act = seqs.shape[0]
             nz = (noise[step_nr - min_context_len].index_select(0, sample_idx).unsqueeze(1) if noise is not None
                   else torch.randn(n_act, 1, D))
-            out, context = model.predict_next_sentence(seqs[:, step_nr - 1:step_nr], context, cache, nz)
-            # ---- finalize_step (scorer.py:243-280)
+            if base:
+                out = model.predict(seqs[:, step_nr - 1:step_nr], cache, nz, sample=opt.sample_latent_variable,
+                                    temperature=self.temperature)                     # lcm/generator.py:248-286
+                cache.increment_step_nr()
+            else:
+                out, context = model.predict_next_sentence(seqs[:, step_nr - 1:step_nr], context, cache, nz)
+            # ---- finalize_step (scorer.py:243-280; lcm/scorer.py:135-169)
             keep_going = text_lens.gt(step_nr + 1)
             preds[:, step_nr - min_context_len] = out[:, -1]
             for idx in (~keep_going).nonzero().flatten().tolist():
@@ -206,8 +215,9 @@ class OracleScorer(OracleGenerator):
             active = keep_going.nonzero().flatten()
             if len(active) == 0:
                 break
-            cache.reorder(active)                                                     # scorer.py:292-314
-            context = context.index_select(0, active)
+            cache.reorder(active)                                                     # scorer.py:292-314; lcm/scorer.py:183-198
+            if not base:
+                context = context.index_select(0, active)
             seqs, preds = seqs.index_select(0, active), preds.index_select(0, active)
             sample_idx, step_scores = sample_idx.index_select(0, active), step_scores.index_select(0, active)
             text_lens = text_lens.index_select(0, active)

@@ -30,28 +30,18 @@ def measure(K):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / K, out
 
-# BF_AB=1: the stacked q / k / v product against three separate ones, alternating in one process (a session reads
-# LCMHIP_STACK when it is created)
+# BF_AB=1: the stacked q / k / v product against three separate ones; BF_AB=rope: the rotation / cache scatter in the
+# stacked product's epilogue against the separate pass.  Alternating in one process (a session takes the model's
+# session_flags when it is created).
 if os.environ.get("BF_AB"):
+    from lcm import _hip
+    flag = _hip.SESSION_SEPARATE_ROPE if os.environ["BF_AB"] == "rope" else _hip.SESSION_SEPARATE_QKV
     for rnd in range(3):
-        for mode in ("1", "0"):
-            os.environ["LCMHIP_STACK"] = mode
-            model._session_pool.clear()
+        for mode in (0, flag):
+            model.session_flags = mode
             dt, _ = measure(10)
-            print(f"round {rnd} LCMHIP_STACK={mode}: {dt * 1e3:.2f} ms per forward", flush=True)
-    os.environ["LCMHIP_STACK"] = "1"
-    model._session_pool.clear()
-# BF_AB_ENV=<name>: any other switch that a session reads when it is created (LCMHIP_FUSE_ROPE ...), 1 against 0
-if os.environ.get("BF_AB_ENV"):
-    name = os.environ["BF_AB_ENV"]
-    for rnd in range(3):
-        for mode in ("1", "0"):
-            os.environ[name] = mode
-            model._session_pool.clear()
-            dt, _ = measure(10)
-            print(f"round {rnd} {name}={mode}: {dt * 1e3:.2f} ms per forward", flush=True)
-    os.environ[name] = "1"
-    model._session_pool.clear()
+            print(f"round {rnd} session_flags={mode}: {dt * 1e3:.2f} ms per forward", flush=True)
+    model.session_flags = 0
 # BF_AB_N128=1: the 256 x 128 tile for the one-tile-per-CU products (attn_out, ffn_out, stacked q / k / v) against the
 # 128 x 128 kernel, alternating in one process (the library reads LCMHIP_BIG256_N128 at every launch)
 if os.environ.get("BF_AB_N128"):

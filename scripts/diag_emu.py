@@ -3,14 +3,13 @@ Prints, for one sentence of the given arch: the contextualizer output against th
 that differ and by how many bf16 steps), then the divergence of the latents per diffusion step against the
 emulation and against the fp32 oracle.
 
-usage: LCMHIP_KEEP_CONTEXT=1 python scripts/diag_emu.py <arch> [mod_gain=.. qk_gain=..]"""
+usage: python scripts/diag_emu.py <arch> [mod_gain=.. qk_gain=..]"""
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-os.environ.setdefault("LCMHIP_KEEP_CONTEXT", "1")
 import torch  # noqa: E402
 
 import oracle  # noqa: E402
@@ -50,6 +49,8 @@ ctx_ref, tr_ref, out_ref = run_oracle(oracle.OracleTwoTower(cfg, sd16))
 
 model = create_two_tower_diffusion_lcm_model(_config(arch), device="cuda:0", dtype=torch.bfloat16)
 model.load_state_dict(sd)
+from lcm import _hip  # noqa: E402
+model.session_flags = _hip.SESSION_KEEP_CONTEXT      # the contextualizer output is read back below
 model.prep_for_denoising(DiffusionLCMGeneratorOptions(**opts))
 bag = LCMIncrementalStateBag(P + 1)
 xc = x.cuda().to(torch.bfloat16)

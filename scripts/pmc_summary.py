@@ -29,7 +29,7 @@ for k in sorted(ft, key=lambda k: -ft[k]):
                  "WRITE_SIZE_KB_avg": round(w_avg, 1), "dispatches_write": wn[k],
                  "hbm_bytes_per_launch_corrected": int((2 * f_avg + w_avg) * 1024)})
 out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (one pass each) -- python3 bench.py --steps 1 --warmup 0 --gen-len 2 "
-                  "--no-cpu-baseline --no-roofline   (LCMHIP_GRAPH=0: kernels are launched one by one, the same launches a replayed graph holds)",
+                  "--no-cpu-baseline --no-roofline   (--no-graph: kernels are launched one by one, the same launches a replayed graph holds)",
        "correction": "gfx950: FETCH_SIZE counts 128-B read requests as 64 B -> doubled; WRITE_SIZE exact; both in KB",
        "kernels": rows}
 json.dump(out, open(os.path.join(dst, RND + "_pmc_hbm_traffic.json"), "w"), indent=1)

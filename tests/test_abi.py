@@ -40,7 +40,10 @@ def test_header_cites_the_reference(hip):
 
 
 def test_version_and_error_channel(hip):
-    assert hip.lib.lcmhip_version() >= 100
+    # the library, the header and the binding agree on the ABI version
+    import re
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'lcmhip.h')).read()
+    assert hip.lib.lcmhip_version() == hip.ABI_VERSION == int(re.search(r'#define LCMHIP_ABI_VERSION (\d+)', header).group(1))
     desc = hip.ModelDesc(sonar_dim=1024, model_dim=1000, max_seq_len=128, timestep_freq_dim=256, dtype=0, norm_eps=1e-5)
     handle = C.c_void_p()
     rc = hip.lib.lcmhip_model_create(C.byref(desc), C.byref(handle))
@@ -64,7 +67,7 @@ def test_model_table_validation_without_gpu(hip):
         assert b"sonar_normalizer.center" in hip.lib.lcmhip_last_error()
         # a session cannot be sized for an unfinished model
         n = C.c_size_t(0)
-        assert hip.lib.lcmhip_session_workspace_bytes(handle, 4, 16, 10, C.byref(n)) == -1
+        assert hip.lib.lcmhip_session_workspace_bytes(handle, 4, 16, 10, 0, C.byref(n)) == -1
         # dtype mismatch and misaligned pointers are rejected at bind time
         shape = (C.c_int64 * 1)(1024)
         assert hip.lib.lcmhip_model_bind_weight(handle, b"sonar_normalizer.center", C.c_void_p(4096), 1, 1, shape) == -1

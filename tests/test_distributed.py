@@ -17,14 +17,25 @@ def _free_port():
 def _worker(rank, world, port, uneven, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from lcm.utils.distributed import all_gather_generations, shard_bounds
+    from lcm.utils.distributed import all_gather_generations, max_shard, shard_bounds
     n_docs = 5 if uneven else 4
     lo, hi = shard_bounds(n_docs, rank, world)
     # "generation" of document g: rows filled with g, length g + 2
-    seqs = torch.stack([torch.full((7, 8), float(g)) for g in range(lo, hi)])
+    seqs = torch.stack([torch.full((7, 8), float(g)) for g in range(lo, hi)]).to(torch.bfloat16)
     lens = torch.tensor([g + 2 for g in range(lo, hi)], dtype=torch.int32)
-    all_seqs, all_lens = all_gather_generations(seqs, lens)
-    torch.save((all_seqs, all_lens), os.path.join(out_dir, f"r{rank}.pt"))
+    # count the collectives the exchange issues: exactly one all-gather when the shard width is known
+    calls = []
+    for name in ("all_gather_into_tensor", "all_gather", "all_reduce", "broadcast", "all_to_all", "gather"):
+        real = getattr(dist, name)
+        setattr(dist, name, (lambda real, name: lambda *a, **k: (calls.append(name), real(*a, **k))[1])(real, name))
+    all_seqs, all_lens = all_gather_generations(seqs, lens, width=max_shard(n_docs, world))
+    assert calls == ["all_gather_into_tensor"], calls
+    # without the width the ranks agree on it first: one more tiny all-reduce, same result
+    again, lens_again = all_gather_generations(seqs, lens)
+    assert calls == ["all_gather_into_tensor", "all_reduce", "all_gather_into_tensor"], calls
+    assert torch.equal(again, all_seqs) and torch.equal(lens_again, all_lens)
+    assert all_seqs.dtype == torch.bfloat16 and all_lens.dtype == torch.int32
+    torch.save((all_seqs.float(), all_lens), os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -148,8 +148,8 @@ def test_fused_rotation_and_cache_scatter_ragged_rows():
     """The q / k / v product of many rows rotates q / k and writes k / v into the cache in its epilogue.  7 x 300
     positions (2100 rows: the last 128-row tile is ragged; 300 positions per document cross the 64-key stages of the
     prefill attention) on a 2-layer, d = 1024 decoder in bf16: the same bits as with the separate
-    rotation-and-scatter pass (LCMHIP_FUSE_ROPE=0, read when a session is created), and the bf16 bar against the oracle."""
-    import os
+    rotation-and-scatter pass (sessions created with SESSION_SEPARATE_ROPE), and the bf16 bar against the oracle."""
+    from lcm import _hip
     from lcm.datasets.batch import EmbeddingsBatch
     from lcm.models.base_lcm import BaseLCModelConfig, TransformerConfig, create_base_lcm_model
     from oracle.weights import synthetic_prompts
@@ -177,13 +177,11 @@ def test_fused_rotation_and_cache_scatter_ragged_rows():
 
     fused, names = fwd_and_kernels()
     assert "ctx.qkv_rope" in names and "ctx.rope_store" not in names, names    # the fused launch is what ran
-    model._session_pool.clear()
-    os.environ["LCMHIP_FUSE_ROPE"] = "0"
+    model.session_flags = _hip.SESSION_SEPARATE_ROPE
     try:
         separate, names = fwd_and_kernels()
     finally:
-        del os.environ["LCMHIP_FUSE_ROPE"]
-        model._session_pool.clear()
+        model.session_flags = 0
     assert "ctx.rope_store" in names and "ctx.qkv_rope" not in names, names
     assert torch.equal(fused, separate)
     sd16 = {k: v.bfloat16().float() for k, v in sd.items()}

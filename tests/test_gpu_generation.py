@@ -123,6 +123,49 @@ def test_batch_of_one_equals_batch(monkeypatch):
         assert (a - b).abs().max() <= 1e-6 * max(1.0, float(b.abs().max()))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_document_shards_equal_one_batch(dtype):
+    """What `bench.py --gpus N` relies on, in one process: 8 documents generated as one batch, as 2 shards of 4 and
+    as 4 shards of 2 (cut by `shard_bounds`, prompts and noise taken by GLOBAL document id, concatenated in rank
+    order like `all_gather_generations` does) give the same generations -- fp32 to 1e-3 / cosine 0.9999, bf16 to
+    the bf16 bar (shards of another size take other tile plans).  Ragged prompts and an EOS vector, so documents
+    also finish at different steps inside every shard.  Only the RCCL call itself is left to a multi-GPU run."""
+    from lcm.utils.distributed import shard_bounds
+    arch = "mini_two_tower_diffusion_lcm"
+    lens = [3, 4, 2, 4, 4, 3, 4, 2]
+    cfg, sd, x, nz = make_problem(arch, 8, 4, 4, prompt_lens=lens)
+    if dtype == torch.bfloat16:
+        sd = {k: oracle_mod.r16(v) for k, v in sd.items()}
+        x = oracle_mod.r16(x)
+    opts = dict(DEFAULT_OPTS, inference_timesteps=10, eos_threshold=0.6)
+    ref = run_oracle(cfg, sd, x, nz, 4, dict(opts, eos_threshold=None), prompt_lens=lens)
+    eos = ref[5][0].seq[5]                       # a sentence document 5 will generate: it stops early there
+    whole, model = run_hip(arch, sd, x, nz, 4, opts, dtype=dtype, prompt_lens=lens, eos_vec=eos)
+    n_finished_early = sum(h[0].seq.shape[0] < n + 4 for h, n in zip(whole.hypotheses, lens))
+    assert n_finished_early >= 1
+    for world in (2, 4):
+        got = []
+        for rank in range(world):
+            lo, hi = shard_bounds(8, rank, world)
+            # the generator consumes noise[step - shortest prompt OF ITS BATCH, document]: a shard whose shortest prompt
+            # is longer starts later in the global table (draws belong to (position, global document id))
+            first = min(lens[lo:hi]) - min(lens)
+            part, _ = run_hip(arch, sd, x[lo:hi], nz[first:, lo:hi], 4, opts, dtype=dtype, prompt_lens=lens[lo:hi], eos_vec=eos,
+                              model=model)
+            got += part.hypotheses
+        assert len(got) == 8
+        for i, (hs, hw) in enumerate(zip(got, whole.hypotheses)):
+            a, b = hs[0].seq.float(), hw[0].seq.float()
+            assert a.shape == b.shape, (world, i, a.shape, b.shape)
+            an, bn = [(t.cpu() - sd["sonar_normalizer.center"]) / sd["sonar_normalizer.scale"] for t in (a, b)]
+            cos = float(torch.nn.functional.cosine_similarity(an, bn, dim=-1).min())
+            if dtype == torch.float32:
+                assert float((an - bn).abs().max()) <= FP32_MAX_ABS and cos >= FP32_COS, (world, i, cos)
+            else:
+                assert cos >= BF16_COS, (world, i, cos)
+    del model
+
+
 def test_no_cpu_fallback():
     from lcm.models.two_tower_diffusion_lcm import create_two_tower_diffusion_lcm_model, lcm_archs
     with pytest.raises(RuntimeError, match="no CPU fallback"):
@@ -256,7 +299,7 @@ def test_1_6b_many_documents_properties(B):
     del model
 
 
-def test_graph_replay_equals_eager(monkeypatch):
+def test_graph_replay_equals_eager():
     """On a non-default stream the denoising loop is recorded into a graph once per active-document count and
     replayed; the outputs must equal the eager launches bit for bit, also when documents leave the batch
     (ragged prompts -> different finishing steps -> several recorded loops)."""
@@ -264,11 +307,16 @@ def test_graph_replay_equals_eager(monkeypatch):
     lens = [2, 4, 3, 4]
     cfg, sd, x, nz = make_problem(arch, 4, 4, 3, prompt_lens=lens)
     opts = dict(DEFAULT_OPTS, inference_timesteps=10)
+    from lcm import _hip
+    from parity_utils import _config
+    from lcm.models.two_tower_diffusion_lcm import create_two_tower_diffusion_lcm_model
     stream = torch.cuda.Stream()
-    monkeypatch.setenv("LCMHIP_GRAPH", "0")
+    model = create_two_tower_diffusion_lcm_model(_config(arch), device="cuda:0", dtype=torch.float32)
+    model.load_state_dict(sd)
+    model.session_flags = _hip.SESSION_NO_GRAPH        # sessions that launch the loop kernel by kernel
     with torch.cuda.stream(stream):
-        eager, model = run_hip(arch, sd, x, nz, 3, opts, prompt_lens=lens)
-    monkeypatch.setenv("LCMHIP_GRAPH", "1")
+        eager, _ = run_hip(arch, sd, x, nz, 3, opts, prompt_lens=lens, model=model)
+    model.session_flags = 0
     with torch.cuda.stream(stream):
         graph, _ = run_hip(arch, sd, x, nz, 3, opts, prompt_lens=lens, model=model)
         again, _ = run_hip(arch, sd, x, nz, 3, opts, prompt_lens=lens, model=model)     # replays of cached graphs

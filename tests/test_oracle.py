@@ -310,3 +310,40 @@ def test_training_shaped_forward_equals_per_position_inference_denoise():
         for j in range(5):
             one = m.denoise(noisy[b:b + 1, j:j + 1], ts[b:b + 1, j:j + 1], ctx[b:b + 1, :min(5, j + s)])
             assert torch.allclose(shifted[b:b + 1, j:j + 1], one, atol=1e-4), (b, j)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_norm_styles_against_torch_modules(dtype):
+    """Independent statements of lcm/nn/normalization.py:16-88 through torch's own modules: `rms` against
+    torch.nn.functional.rms_norm (fp32 statistics, cast back, then the weight: fairseq2's RMSNorm order), `standard`
+    against torch.nn.LayerNorm with weight and bias, `fp32` against LayerNorm evaluated on fp32 copies and cast back
+    (:17-33), `unit` against LayerNorm(elementwise_affine=False) (:56-70)."""
+    from oracle.model import norm
+    torch.manual_seed(3)
+    d, eps = 256, 1e-5
+    x = (torch.randn(7, 5, d) * 3.0 + 0.5).to(dtype)
+    w, b = (1.0 + 0.3 * torch.randn(d)).to(dtype), (0.2 * torch.randn(d)).to(dtype)
+    sd = {"n.weight": w, "n.bias": b}
+    # rms: normalise in fp32 without a weight, cast to the input dtype, multiply by the weight in that dtype
+    want = F.rms_norm(x.float(), (d,), None, eps).to(dtype) * w
+    assert torch.equal(norm(x, sd, "n", "rms", eps), want)
+    ln = torch.nn.LayerNorm(d, eps=eps, dtype=dtype)
+    with torch.no_grad():
+        ln.weight.copy_(w)
+        ln.bias.copy_(b)
+    assert torch.equal(norm(x, sd, "n", "standard", eps), ln(x))
+    ln32 = torch.nn.LayerNorm(d, eps=eps, bias=False)
+    with torch.no_grad():
+        ln32.weight.copy_(w.float())
+    assert torch.equal(norm(x, sd, "n", "fp32", eps), ln32(x.float()).to(dtype))
+    unit = torch.nn.LayerNorm(d, eps=eps, elementwise_affine=False)
+    assert torch.equal(norm(x, {}, "n", "unit", eps), unit(x))
+    # the definitions themselves, in float64
+    x64 = x.double()
+    rms64 = x64 / (x64.pow(2).mean(-1, keepdim=True) + eps).sqrt() * w.double()
+    tol = 1e-5 if dtype == torch.float32 else 4e-2
+    assert (norm(x, sd, "n", "rms", eps).double() - rms64).abs().max() < tol * rms64.abs().max()
+    mu, var = x64.mean(-1, keepdim=True), x64.var(-1, unbiased=False, keepdim=True)
+    ln64 = (x64 - mu) / (var + eps).sqrt()
+    assert (norm(x, {}, "n", "unit", eps).double() - ln64).abs().max() < tol * ln64.abs().max()
+    assert (norm(x, sd, "n", "standard", eps).double() - (ln64 * w.double() + b.double())).abs().max() < tol * 8

@@ -63,6 +63,44 @@ def test_gemm_static_equals_gemm_with_workspace(hip, dtype):
             assert (got.float() - full).abs().max() <= tol * max(1.0, float(full.abs().max())), (dtype, epi)
 
 
+def test_gemm_static_allocates_nothing_and_runs_under_capture(hip):
+    """What the entry point is for: (1) after lcmhip_static_init() (outside any capture) a call changes the device's
+    free memory by nothing, warmed or not; (2) a call recorded into a HIP graph (stream capture forbids allocation) and
+    replayed gives the bits of the eager call."""
+    hip.check(hip.lib.lcmhip_static_init())
+    hip.check(hip.lib.lcmhip_static_init())                     # idempotent
+    M, N, K = 128, 2048, 2048
+    A, W, b, _, _ = _problem(torch.bfloat16, M, N, K, 11)
+    eager = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(3):
+        hip.check(_call(hip, True, A, W, None, b, None, None, eager, hip.EPI_STORE, None))
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free1 == free0, (free0, free1)
+    # under capture, on a side stream: the launches are recorded (nothing runs), then the graph is replayed
+    captured = torch.zeros_like(eager)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        graph.capture_begin()
+        rc = _call(hip, True, A, W, None, b, None, None, captured, hip.EPI_STORE, None)
+        graph.capture_end()
+    hip.check(rc)
+    torch.cuda.synchronize()
+    assert not captured.any()                                    # capture executes nothing
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(captured, eager)
+    captured.zero_()
+    graph.replay()                                               # the static array keeps the first replay's contents
+    torch.cuda.synchronize()
+    assert torch.equal(captured, eager)
+    del graph
+
+
 def test_gemm_static_swiglu_and_limits(hip):
     A, W, b, _, _ = _problem(torch.bfloat16, 64, 512, 1024, 3)
     _, W2, b2, _, _ = _problem(torch.bfloat16, 64, 512, 1024, 4)
