@@ -189,3 +189,37 @@ def test_fused_rotation_and_cache_scatter_ragged_rows():
     c, s = sd16["frontend.sonar_normalizer.center"], sd16["frontend.sonar_normalizer.scale"]
     cos = torch.nn.functional.cosine_similarity((fused.cpu().float() - c) / s, (ref16 - c) / s, dim=-1)
     assert cos.min() >= BF16_COS, float(cos.min())
+
+
+@pytest.mark.parametrize("arch,sample", [("mini_base_lcm", True), ("mini_base_lcm", False), ("toy_base_lcm", True)])
+def test_base_teacher_forced_scorer(arch, sample):
+    """LCMScorer (reference lcm/inference/lcm/scorer.py:19-198) against the oracle's restatement of it: ragged
+    documents, min_context_len 1 and 3, with and without sampling noise.  Three HIP evaluations must agree with the
+    oracle and with each other: all positions in one pass (the default), the reference's step-by-step loop on the KV
+    cache, and the loop with the cache disabled."""
+    from lcm.datasets.batch import EmbeddingsBatch, PaddingMask
+    from lcm.inference.lcm import LCMGeneratorOptions, LCMScorer
+    from lcm.models.base_lcm import create_base_lcm_model
+    lens = [7, 4, 6, 7, 5]
+    cfg, sd, x, nz = make_base_problem(arch, 5, 7, 0, prompt_lens=lens)
+    opts = dict(OPTS, sample_latent_variable=sample, lcm_temperature=0.4)
+    model = create_base_lcm_model(base_config(arch), device="cuda:0", dtype=torch.float32)
+    model.load_state_dict(sd)
+    batch = EmbeddingsBatch(x.cuda(), PaddingMask(torch.tensor(lens, device="cuda:0"), 7))
+    has_norm = "frontend.sonar_normalizer.center" in sd
+    for mcl in (1, 3):
+        ref = oracle.OracleScorer(oracle.OracleBaseLCM(cfg, sd), oracle.GenOptions(**opts))(
+            x, text_lens=torch.tensor(lens), min_context_len=mcl, noise=nz)
+        runs = {}
+        for name, one_pass, no_cache in (("one pass", True, False), ("steps, KV cache", False, False), ("steps, no cache", False, True)):
+            scorer = LCMScorer(model, LCMGeneratorOptions(**opts))
+            scorer.one_pass = one_pass
+            out = scorer(batch, min_context_len=mcl, disable_cache=no_cache, noise=nz.cuda())
+            assert [h[0].seq.shape[0] for h in out.hypotheses] == [n - mcl for n in lens], name
+            worst, cos = compare(out.hypotheses, ref, _norm_sd(sd)) if has_norm else compare_raw(out.hypotheses, ref)
+            assert worst <= FP32_MAX_ABS and cos >= FP32_COS, (name, mcl, worst, cos)
+            runs[name] = out.hypotheses
+        for name in ("steps, KV cache", "steps, no cache"):
+            for ha, hb in zip(runs["one pass"], runs[name]):
+                a, b = ha[0].seq.float(), hb[0].seq.float()
+                assert (a - b).abs().max() <= 1e-3 * max(1.0, float(b.abs().max())), name

@@ -347,3 +347,24 @@ def test_norm_styles_against_torch_modules(dtype):
     ln64 = (x64 - mu) / (var + eps).sqrt()
     assert (norm(x, {}, "n", "unit", eps).double() - ln64).abs().max() < tol * ln64.abs().max()
     assert (norm(x, sd, "n", "standard", eps).double() - (ln64 * w.double() + b.double())).abs().max() < tol * 8
+
+
+def test_base_scorer_equals_one_causal_forward():
+    """The base LCM's teacher-forced scorer (lcm/inference/lcm/scorer.py:19-198: one cached decode step per sentence,
+    gold inputs) is one causal forward over the gold sequence: prediction j of the scorer == position j - 1 of
+    `predict` over the whole document, for ragged documents and min_context_len 1 and 3."""
+    cfg = oracle.get_base_arch("mini_base_lcm")
+    sd = oracle.init_state_dict(cfg, seed=3, qk_gain=2.0)
+    lens = [6, 4, 5]
+    x = synthetic_prompts(oracle.load_dummy_normalizer(), 3, 6, seed=9)
+    for i, n in enumerate(lens):
+        x[i, n:] = 0
+    model = oracle.OracleBaseLCM(cfg, sd)
+    full = model.predict(x)                                                  # (3, 6, D): all positions, no cache
+    for mcl in (1, 3):
+        hyps = oracle.OracleScorer(model, oracle.GenOptions(eos_threshold=None, sample_latent_variable=False))(
+            x, text_lens=torch.tensor(lens), min_context_len=mcl)
+        for i, n in enumerate(lens):
+            got = hyps[i][0].seq
+            assert got.shape == (n - mcl, 1024)
+            assert torch.allclose(got, full[i, mcl - 1:n - 1], atol=1e-4, rtol=1e-4)
