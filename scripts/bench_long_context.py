@@ -38,7 +38,28 @@ table = {r["name"]: dict(launches=r["launches"], ms=round(r["total_ms"], 2),
                          tflops=round(r["flops"] / r["total_ms"] / 1e9, 1) if r["total_ms"] > 0 else None)
          for r in rows if r["launches"]}
 steps = len(model.noise_scheduler.timesteps)
+# copy calibration on THIS device, in the same process: what a read-once / write-once stream reaches here.  The
+# cross-attention stream cannot be faster than that, so its rate is reported as a fraction of it (devices of the pool
+# differ by several per cent in this number).
+from lcm import _hip
+nbytes = 1 << 30
+src = torch.empty(nbytes, dtype=torch.uint8, device=dev).random_(0, 255)
+dst = torch.empty_like(src)
+st = _hip.stream_ptr(dev)
+best = 0.0
+for nt in (0, 1):
+    for _ in range(2):
+        _hip.check(_hip.lib.lcmhip_stream_copy(_hip.ptr(src), _hip.ptr(dst), nbytes, nt, st))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        _hip.check(_hip.lib.lcmhip_stream_copy(_hip.ptr(src), _hip.ptr(dst), nbytes, nt, st))
+    e1.record(); torch.cuda.synchronize()
+    best = max(best, 2.0 * nbytes * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+attn_gbps = table.get("den.cross_attn", {}).get("gbps")
 print(json.dumps({"workload": f"two_tower_diffusion_lcm_1_6B long context: {B} docs, prompt {P}, {G} generated, {steps} DDIM steps, CFG, bf16",
                   "sentence_embeddings_per_s_at_context": round(B / per_sentence, 1), "ms_per_sentence_step": round(per_sentence * 1e3, 1),
                   "ms_per_diffusion_step": round(per_sentence * 1e3 / steps, 3), "prefill_plus_first_sentence_s": round(t1, 2),
+                  "copy_calibration_gbps": round(best, 1), "workspace_address": hex(sess.workspace.data_ptr()),
+                  "cross_attn_fraction_of_copy_rate": round(attn_gbps / best, 3) if attn_gbps else None,
                   "kernels": table}))

@@ -8,6 +8,8 @@ st = _hip.stream_ptr(dev)
 ITERS = int(os.environ.get("GB_ITERS", "20"))
 NO_TORCH = bool(os.environ.get("GB_NO_TORCH"))       # under a counter-collecting profiler: only this library's kernels
 ROWS = [int(v) for v in os.environ.get("GB_ROWS", "256,1024,4096").split(",")]
+# split-K workspace handed to the library, as a session does for every linear product (MiB; 0: none)
+WS = torch.empty(int(os.environ.get("GB_WS_MB", "96")) << 18, device=dev, dtype=torch.float32) if int(os.environ.get("GB_WS_MB", "96")) else None
 
 def bench(M, N, K, epi):
     A = torch.randn(M, K, device=dev).bfloat16()
@@ -17,7 +19,7 @@ def bench(M, N, K, epi):
     out = torch.zeros(M, N, device=dev, dtype=torch.float32 if f32_out else torch.bfloat16)
     def run():
         _hip.check(_hip.lib.lcmhip_gemm(_hip.ptr(A), K, _hip.ptr(W), _hip.ptr(W2), None, None, None, _hip.ptr(out), N,
-                                        M, N, K, epi, _hip.BF16, None, 0, st))
+                                        M, N, K, epi, _hip.BF16, _hip.ptr(WS), WS.numel() * 4 if WS is not None else 0, st))
     for _ in range(3): run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
