@@ -234,6 +234,8 @@ bool gemm_big_applicable(const GemmArgs& a, bool may_split);   // gemm_big.hip: 
 int gemm_big_splits(const GemmArgs& a, int max_splits);
 int launch_gemm_big(const GemmArgs& a, int epi, int splits, int m_rows, hipStream_t st);
 
+constexpr double kDmaChunk256 = 256.0;   // bytes of K per tile row and pipeline stage of the LDS-DMA tiles
+
 struct Plan {
     int wm, wn, tn;    // wave grid and weight tiles per wave
     int n_tiles, m_tiles, splits;
@@ -289,6 +291,25 @@ static Plan make_plan(const GemmArgs& a, bool may_split) {
         pl.splits = (nchunks + cps - 1) / cps;
     }
     return pl;
+}
+
+// Does a K split followed by a finishing pass (lcmhip_gemm's form) beat the unsplit launch?  Estimate in microseconds
+// from what the LDS-DMA tiles were measured at: a workgroup advances one 256-byte K chunk per 0.7 us (128-row tile, one
+// workgroup per CU) or 0.55 us (64-row tile, two per CU), workgroups beyond one round of the chip queue behind the
+// first, and the finishing pass costs a launch (4 us) plus its slab traffic at 4 TB/s.  Checked against bf16 shapes of
+// 64 to 1024 rows, N = 2048, K = 2048 / 5632: it splits 64 x 2048 x 2048 (9 against 12 us), 256 and 512 x 2048 x 5632
+// (16.0 against 27.5 us, 24.5 against 28.5 us) and leaves 384 and 768 x 2048 x 2048 (12.2 against 17.0 us, 13.0 against
+// 20.4 us) unsplit.
+static bool split_pays_with_finish(const GemmArgs& a, const Plan& pl) {
+    const bool tall = pl.wm == 4;
+    const double per_chunk = tall ? 0.7 : 0.55;
+    const int round = 256 * (tall ? 1 : 2);
+    const double nch = (double)a.K * 2.0 / kDmaChunk256;
+    const int wgs = pl.n_tiles * pl.m_tiles;
+    auto rounds = [&](int n) { return (double)((n + round - 1) / round); };
+    const double unsplit = rounds(wgs) * nch * per_chunk;
+    const double split = rounds(wgs * pl.splits) * (nch / pl.splits) * per_chunk + 4.0 + (pl.splits + 1.0) * (double)a.M * a.N * 4.0 / 4.0e6;
+    return split < unsplit;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -626,8 +647,15 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
         return LCMHIP_OK;
     }
     const bool can_split = a.partial != nullptr && a.epilogue != LCMHIP_EPI_SWIGLU;
-    if (gemm_big_applicable(a, can_split)) {
-        int s = can_split ? gemm_big_splits(a, a.max_splits) : 1;
+    // A K split here is followed by a finishing pass over the slabs (unlike the pending form, whose consumer sums
+    // them), which a many-row product never earns back: 1024 x 2048 x 2048 took 24.4 us split four ways on the
+    // matrix-core kernel against 13.7 us unsplit, the residual update 26.0 against 15.9 us, 1024 x 2048 x 5632 36.6
+    // against 30.5 us.  So the matrix-core kernels run unsplit in this form ...
+    if (gemm_big_applicable(a, false)) {
+        // (one exception, measured: at most one 128 x 128 tile per CU and a long K loop -- 2048 x 2048 x 5632: 54.7 us
+        // split in two against 59.5-65 us; with K = 2048 the split loses, 30.7 against 25.4-27.2 us)
+        const int tiles = (a.N / 128) * ((a.M + 127) / 128);
+        int s = (can_split && a.stack <= 1 && tiles <= 256 && a.K >= 4096) ? gemm_big_splits(a, a.max_splits) : 1;
         if ((size_t)s * a.M * a.N * 4 > a.partial_bytes) s = 1;
         if (s > 1) {
             LCM_TRY(launch_gemm_big(a, EPI_PARTIAL, s, a.M, st));
@@ -637,6 +665,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     }
     Plan pl = make_plan(a, can_split);
     if (can_split && (size_t)pl.splits * a.M * a.N * 4 > a.partial_bytes) pl.splits = 1;
+    // ... and the weight-streaming tiles split only where the estimate says the finishing pass is paid for
+    if (pl.splits > 1 && a.dtype == LCMHIP_BF16 && !split_pays_with_finish(a, pl)) pl.splits = 1;
     if (pl.splits > 1) {
         LCM_TRY(a.dtype == LCMHIP_BF16 ? launch_plan<bf16_t>(a, pl, EPI_PARTIAL, st) : launch_plan<float>(a, pl, EPI_PARTIAL, st));
         return a.dtype == LCMHIP_BF16 ? launch_finish<bf16_t>(a, pl.splits, st) : launch_finish<float>(a, pl.splits, st);
