@@ -482,7 +482,7 @@ int launch_attention_q(const AttnQ& qa, const void* kc, const void* vc, const in
     LCM_REQUIRE(max_keys >= 1 && max_keys <= cap, "attention: key range exceeds the cache");
     LCM_REQUIRE((qa.q != nullptr) != (qa.partial != nullptr), "attention: exactly one query source");
     if (n_docs == 0) return LCMHIP_OK;
-    static const int prefill_min = [] { const char* e = getenv("LCMHIP_PREFILL_MIN"); return e ? atoi(e) : 4; }();   // shortest causal query block that takes the matrix-core kernel
+    constexpr int prefill_min = 4;   // shortest causal query block that takes the matrix-core kernel
     if (causal && dtype == LCMHIP_BF16 && qa.q != nullptr && s >= prefill_min && base_keys_dev == nullptr) {
         const int qtiles = (s + 63) / 64;
         hipLaunchKernelGGL(k_attention_prefill, dim3((unsigned)(n_docs * n_heads * qtiles)), dim3(256), 0, st,

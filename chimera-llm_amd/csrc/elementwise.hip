@@ -711,12 +711,11 @@ int launch_norm_modulate(float* x, const void* w, const void* b, const float* sh
         }
     }
     if (pend) {
-        static const int fast = [] { const char* e = getenv("LCMHIP_NORM_FAST"); return e ? atoi(e) : 1; }();
         bool done = false;
-        if (fast && dtype == LCMHIP_BF16)
+        if (dtype == LCMHIP_BF16)
             done = norm_kind == LCMHIP_NORM_RMS ? try_norm_pending<bf16_t, LCMHIP_NORM_RMS>(x, w, b, shift, scale, y, rows, rows_norm, dim, eps, pd, rs, st)
                                                 : try_norm_pending<bf16_t, LCMHIP_NORM_LAYERNORM>(x, w, b, shift, scale, y, rows, rows_norm, dim, eps, pd, rs, st);
-        else if (fast && dtype == LCMHIP_F32)
+        else if (dtype == LCMHIP_F32)
             done = norm_kind == LCMHIP_NORM_RMS ? try_norm_pending<float, LCMHIP_NORM_RMS>(x, w, b, shift, scale, y, rows, rows_norm, dim, eps, pd, rs, st)
                                                 : try_norm_pending<float, LCMHIP_NORM_LAYERNORM>(x, w, b, shift, scale, y, rows, rows_norm, dim, eps, pd, rs, st);
         if (done) {

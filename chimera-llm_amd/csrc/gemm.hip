@@ -241,17 +241,6 @@ struct Plan {
     int n_tiles, m_tiles, splits;
 };
 
-// 0: register-staged kernels only; 1: LDS-DMA staging for the 128-row bf16 tile; 2 (default): also for the 64-row tile
-static int dma_mode() {
-    static const int v = [] { const char* e = getenv("LCMHIP_GEMM_DMA"); return e ? atoi(e) : 2; }();
-    return v;
-}
-
-static int tall_mode() {
-    static const int v = [] { const char* e = getenv("LCMHIP_TALL"); return e ? atoi(e) : 1; }();   // 0: 64 x 64 tiles only; 1 (default): 128 x 64 tiles with 8 waves for more than 64 rows
-    return v;
-}
-
 static Plan make_plan(const GemmArgs& a, bool may_split) {
     const int rows = a.M;   // rows that go through the matrix cores
     const bool dual = a.epilogue == LCMHIP_EPI_SWIGLU;
@@ -259,10 +248,10 @@ static Plan make_plan(const GemmArgs& a, bool may_split) {
     Plan pl{};
     // bf16 with at most 64 rows: the 64-row LDS-DMA tile also for fewer than 33 rows (the unused rows cost matrix-core
     // work only; measured on the SwiGLU up-projection at 16 rows: 38.7 us register-staged 32 x 256 -> 17.5 us)
-    const bool dma64 = a.dtype == LCMHIP_BF16 && dma_mode() >= 2;
+    const bool dma64 = a.dtype == LCMHIP_BF16;      // bf16 always takes the LDS-DMA tiles
     if (!dma64 && rows <= 32 && wrows % 256 == 0) { pl.wm = 1; pl.wn = 4; pl.tn = 4; }         // 32 x 256
     else if (!dma64 && rows <= 64 && wrows % 128 == 0 && wrows >= 128 * 192) { pl.wm = 2; pl.wn = 2; pl.tn = 4; }   // 64 x 128
-    else if (rows > 64 && tall_mode() != 0) { pl.wm = 4; pl.wn = 2; pl.tn = 2; }      // 128 x 64, 8 waves: every weight row read by one workgroup
+    else if (rows > 64) { pl.wm = 4; pl.wn = 2; pl.tn = 2; }      // 128 x 64, 8 waves: every weight row read by one workgroup
     else { pl.wm = 2; pl.wn = 2; pl.tn = 2; }                                        // 64 x 64, two per CU
     const int bm = 32 * pl.wm, bnr = 16 * pl.tn * pl.wn;
     pl.n_tiles = wrows / bnr;
@@ -272,18 +261,16 @@ static Plan make_plan(const GemmArgs& a, bool may_split) {
         const int nchunks = (int)((size_t)a.K * dtype_size(a.dtype) / kChunkBytes);
         const int tiles = pl.n_tiles * pl.m_tiles;
         // enough workgroups to put two on every CU, every split at least one chunk
-        static const int target2 = [] { const char* e = getenv("LCMHIP_SPLIT_TARGET"); return e ? atoi(e) : 512; }();
-        static const int target1 = [] { const char* e = getenv("LCMHIP_SPLIT_TARGET_TALL"); return e ? atoi(e) : 256; }();
-        const int target = pl.wm == 4 ? target1 : target2;   // the tall tile fits once per CU
+        const int target = pl.wm == 4 ? 256 : 512;           // the tall tile fits once per CU (128 / 192 / 320 / 512
+                                                             // and 256 / 384 / 768 measured end to end: no better)
         int s = (target + tiles - 1) / tiles;
         s = std::min(s, nchunks);
         // the LDS-DMA tall tile wants at least two 512-byte chunks per split (four stages of its pipeline):
         // measured 10.6 -> 10.1 us on 128 x 2048 x 2048; the 64-row tile is faster with one (7.1 vs 7.7 us)
-        // (LCMHIP_TALL_MIN_CHUNKS; re-measured with the DMA spread over the k-steps: one chunk per split makes self_ov itself
-        // 9 % faster, 6.2 against 6.9 us, and the whole loop 1.5 % slower, 1313 against 1333 sentence-embeddings/s: twice the
-        // slabs for the next norm kernel)
-        static const int tall_min = [] { const char* e = getenv("LCMHIP_TALL_MIN_CHUNKS"); return e ? std::max(1, atoi(e)) : 2; }();
-        if (pl.wm == 4 && a.dtype == LCMHIP_BF16 && dma_mode() != 0) s = std::min(s, std::max(1, nchunks / tall_min));
+        // (re-measured with the DMA spread over the k-steps: one chunk per split makes self_ov itself 9 % faster, 6.2
+        // against 6.9 us, and the whole loop 1.5 % slower, 1313 against 1333 sentence-embeddings/s: twice the slabs for
+        // the next norm kernel)
+        if (pl.wm == 4 && a.dtype == LCMHIP_BF16) s = std::min(s, std::max(1, nchunks / 2));
         s = std::min(s, a.max_splits > 0 ? a.max_splits : 64);
         pl.splits = std::max(1, s);
         // re-balance: every split gets the same number of chunks where possible
@@ -319,12 +306,6 @@ static bool split_pays_with_finish(const GemmArgs& a, const Plan& pl) {
 // The LDS image is lane-linear, so bank conflicts of the fragment reads (16 rows x one 16-byte piece) are removed on
 // the SOURCE side: slot s of tile row r holds K piece s ^ (r % 16).
 // ------------------------------------------------------------------------------------------------
-#ifndef LCM_DMA_ROTATE
-#define LCM_DMA_ROTATE 1                             // 0: every workgroup walks K from its first chunk (A/B builds)
-#endif
-#ifndef LCM_DMA_INTERLEAVE
-#define LCM_DMA_INTERLEAVE 1                         // 0: the DMA of a chunk as one burst behind the barrier (A/B builds)
-#endif
 constexpr int kDmaChunk = 256;                       // bytes of K per tile row and stage
 constexpr int dma_stage_bytes(int wm) { return (32 * wm + 64) * kDmaChunk; }   // activation rows + 64 weight rows
 constexpr int dma_lds_bytes(int wm) { return 3 * dma_stage_bytes(wm); }         // 144 KB (128 rows) / 96 KB (64 rows)
@@ -385,15 +366,11 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_dma(GemmArgs p) {
             }
         }
     }
-#if LCM_DMA_ROTATE
     // A workgroup walks its K range from a chunk of its own and wraps around: the workgroups of an XCD (ids i, i + 8,
     // ...) all read the SAME activation chunk from their L2 at about the same time otherwise (every one of them needs the
     // whole row tile), and those reads queue on the few L2 channels that hold it.
     const int rot = nc > 1 ? (int)(((blockIdx.x >> 3) * 3u + (blockIdx.x & 7u)) % (unsigned)nc) : 0;
     auto chunk_of = [&](int c) { const int r = c + rot; return r >= nc ? r - nc : r; };
-#else
-    auto chunk_of = [&](int c) { return c; };
-#endif
     auto stage = [&](int c, int buf) {
         char* dst = smem + buf * kDmaStage + wid * 1024;
         const uint32_t koff = (uint32_t)chunk_of(c) * kDmaChunk;
@@ -419,7 +396,6 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_dma(GemmArgs p) {
 
     stage(0, 0);
     if (nc > 1) stage(1, 1);
-#if LCM_DMA_INTERLEAVE
     // one DMA instruction of chunk c + 2 (piece j of this wave)
     auto stage_piece = [&](int c, int buf, int j) {
         char* dst = smem + buf * kDmaStage + wid * 1024 + j * NW * 1024;
@@ -468,37 +444,6 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_dma(GemmArgs p) {
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-#else
-    for (int c = 0; c < nc; ++c) {
-        // chunk c has landed (this wave's part: everything but the NG newest DMA instructions = chunk c + 1) ...
-        if (c + 1 < nc) {
-            if constexpr (NG == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        // ... for every wave, and every wave is done with chunk c - 1, whose stage is refilled next
-        __builtin_amdgcn_s_barrier();
-        if (c + 2 < nc) stage(c + 2, (c + 2) % 3);
-        const char* base = smem + (c % 3) * kDmaStage;
-        bf16x8 w[4][2], x[4][2];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int slot = ((4 * ks + kq) ^ frow) * 16;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) w[ks][t] = *reinterpret_cast<const bf16x8*>(base + w_off + t * 16 * kDmaChunk + slot);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) x[ks][t] = *reinterpret_cast<const bf16x8*>(base + x_off + t * 16 * kDmaChunk + slot);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-                for (int tm = 0; tm < 2; ++tm)
-                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ks][tn], x[ks][tm], acc[tn][tm], 0, 0, 0);
-    }
-#endif
 #ifdef LCM_DMA_STAMPS
     if (stamps && tid == 0) stamps[2] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -516,9 +461,8 @@ static int launch_dma(const GemmArgs& a, const Plan& pl, int epi, hipStream_t st
     dim3 grid(pl.n_tiles, pl.splits, pl.m_tiles), block(128 * WM);
     constexpr int kDmaLds = dma_lds_bytes(WM);
     // Non-temporal weight DMA when a single row tile reads every weight row once (the weights of a model do not
-    // fit the caches between launches): +1 % end to end.  LCMHIP_GEMM_NT=0 switches it off.
-    static const int nt_mode = [] { const char* e = getenv("LCMHIP_GEMM_NT"); return e ? atoi(e) : 1; }();
-    const bool nt = nt_mode != 0 && pl.m_tiles == 1;
+    // fit the caches between launches): +1 % end to end.
+    const bool nt = pl.m_tiles == 1;
 #define LCM_DMA1(E, N)                                                                                              \
     {                                                                                                               \
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_dma<E, WM, N>),    \
@@ -562,11 +506,11 @@ template <typename T>
 static int launch_plan(const GemmArgs& a, const Plan& pl, int epi, hipStream_t st) {
     if (pl.wm == 1) return launch_cfg<T, 1, 4, 4>(a, pl, epi, st);
     if (pl.wm == 4 && pl.wn == 2) {
-        if (std::is_same<T, bf16_t>::value && dma_mode() != 0) return launch_dma<4>(a, pl, epi, st);
+        if (std::is_same<T, bf16_t>::value) return launch_dma<4>(a, pl, epi, st);
         return launch_cfg<T, 4, 2, 2>(a, pl, epi, st);
     }
     if (pl.tn == 4) return launch_cfg<T, 2, 2, 4>(a, pl, epi, st);
-    if (std::is_same<T, bf16_t>::value && dma_mode() >= 2) return launch_dma<2>(a, pl, epi, st);
+    if (std::is_same<T, bf16_t>::value) return launch_dma<2>(a, pl, epi, st);
     return launch_cfg<T, 2, 2, 2>(a, pl, epi, st);
 }
 

@@ -339,16 +339,10 @@ __global__ __launch_bounds__(128 * WMV) void k_gemm_big(GemmArgs p) {
 constexpr int kHT = 128 * kRowB;          // one half-tile: 128 rows x 128 bytes
 constexpr int kBig256Lds = 2 * 4 * kHT;   // 128 KB
 
-// WT = weight-row tiles per wave: 4 (256 weight rows per tile, the description above) or 2 (a 256 x 128 tile for products
-// with too few 256 x 256 tiles: wave tile 128 x 32, one weight half-tile per K tile, 8 matrix-core instructions per
-// phase, the same barriers and hazards; linear epilogues only).
-// HR (256-row weight tile only): the fragment reads are issued by hand (inline-asm ds_read_b128) and retired with counted
-// lgkmcnt waits instead of the compiler's, which drains every pending LDS read before a product that needs any.
-template <int EPI, int WT, bool HR = false>
+template <int EPI>
 __global__ __launch_bounds__(512) void k_gemm_big256(GemmArgs p) {
-    static_assert(!HR || WT == 4, "hand-issued reads exist for the 256 x 256 tile only");
     constexpr bool DUAL = (EPI == LCMHIP_EPI_SWIGLU);
-    static_assert(WT == 4 || (WT == 2 && !DUAL), "the 256 x 128 tile has no SwiGLU pairing");
+    constexpr int WT = 4;                     // weight-row tiles of 16 per wave
     constexpr int BNW = 64 * WT;              // weight rows of the tile
     extern __shared__ __attribute__((aligned(1024))) char smem256[];
     char* const smem = smem256;
@@ -399,7 +393,7 @@ __global__ __launch_bounds__(512) void k_gemm_big256(GemmArgs p) {
             w_step_j = 32u * kbytes;
             w_step_h = 64u * kbytes;
         } else {
-            offW0 = (uint32_t)(bx * BNW + r) * kbytes + piece_off;   // WT == 2: only half 0 is ever staged
+            offW0 = (uint32_t)(bx * BNW + r) * kbytes + piece_off;
             w_step_j = 64u * kbytes;
             w_step_h = 128u * kbytes;
         }
@@ -431,20 +425,13 @@ __global__ __launch_bounds__(512) void k_gemm_big256(GemmArgs p) {
     const int frow = lane & 15;
     const int fsw = (frow >> 1) & 7;
     const int x_off = wr * kHT + frow * kRowB;                               // + 16 tm rows
-    const int w_off = WT == 4 ? (2 + (wc >> 1)) * kHT + ((wc & 1) * 64 + frow) * kRowB   // + 16 tn rows
-                              : 2 * kHT + (wc * 32 + frow) * kRowB;
+    const int w_off = (2 + (wc >> 1)) * kHT + ((wc & 1) * 64 + frow) * kRowB;   // + 16 tn rows
     const int slot0 = (((lane >> 4)) ^ fsw) * 16, slot1 = ((4 + (lane >> 4)) ^ fsw) * 16;
 
     // prologue: K tile 0 whole; of K tile 1 the weight halves and activation half 0 (nk >= 4: K is a multiple of 256)
-    if constexpr (WT == 4) {
-        stage_w(0, 0, 0); stage_w(1, 0, 0); stage_x(0, 0, 0); stage_x(1, 0, 0);
-        stage_w(0, 1, 1); stage_w(1, 1, 1); stage_x(0, 1, 1);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-        stage_w(0, 0, 0); stage_x(0, 0, 0); stage_x(1, 0, 0);
-        stage_w(0, 1, 1); stage_x(0, 1, 1);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    }
+    stage_w(0, 0, 0); stage_w(1, 0, 0); stage_x(0, 0, 0); stage_x(1, 0, 0);
+    stage_w(0, 1, 1); stage_w(1, 1, 1); stage_x(0, 1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
     // fragments: w[ks][tn] = the wave's 64 weight rows; x?[ks][b] = activation row tiles 2 i + b of phase i
@@ -465,106 +452,10 @@ __global__ __launch_bounds__(512) void k_gemm_big256(GemmArgs p) {
             _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                  \
                 acc[TN0 + a][2 * (I) + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ks][TN0 + a], XF[ks][b], acc[TN0 + a][2 * (I) + b], 0, 0, 0);
 
-    // 4 products of one k-step: weight tiles 0, 1 x the phase's two activation tiles (the 256 x 128 tile)
-#define LCM_MMA4(XF, I, KS)                                                                                \
-    _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                          \
-        _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                      \
-            acc[a][2 * (I) + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[KS][a], XF[KS][b], acc[a][2 * (I) + b], 0, 0, 0);
-
     bf16x8 w[2][WT], xe[2][2], xo[2][2];
-    if constexpr (HR) {
-        // Reads retire in order, so "at most n younger reads pending" retires a fragment.  The compiler does not know that
-        // an asm result is still in flight: every wait is followed by a scheduling fence so that no product moves above
-        // it, and nothing copies a fragment -- the next K tile's weight fragments are read IN PLACE, each pair of weight
-        // tiles right behind its last products of phase 3 (tiles 0-1 first, then 2-3), and retired by the counted waits
-        // of the next tile's phase 0.  LDS reads per phase: 4 / 4 / 4 / 12, as with the compiler-issued reads.
-        //   phase 0: read X1 | DMA X-half 1 of kt+1 | retire X0, W01 (8 younger) | products W01 | retire W23 (4) | products W23
-        //   phase 1: barrier A | read X2 | DMA W-half 0 of kt+2 | retire X1 (4) | 16 products
-        //   phase 2: read X3 | DMA W-half 1 of kt+2 | retire X2 (4) | 16 products
-        //   phase 3: vmcnt, lgkmcnt(0), barrier B | DMA X-half 0 of kt+2 | read X0' | products W01 | read W01' | products W23 | read W23'
-        const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
-        // fragment bases of K-tile buffer 0; buffer 1 is 64 KB further (beyond the 16-bit offset field: added per read)
-        const uint32_t xb0 = lds0 + (uint32_t)(x_off + slot0), xb1 = lds0 + (uint32_t)(x_off + slot1);
-        const uint32_t wb0 = lds0 + (uint32_t)(w_off + slot0), wb1 = lds0 + (uint32_t)(w_off + slot1);
-#define LCM_DSR(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "i"(OFF))
-#define LCM_LGKM(N) asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : "memory")
-#define LCM_HPIN() __builtin_amdgcn_sched_barrier(0)
-#define LCM_HRD_X2(DST, BUF, I)                                                      \
-    _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                  \
-        LCM_DSR(DST[0][b], xb0 + (BUF) * (4u * kHT), (2 * (I) + b) * 16 * kRowB);    \
-        LCM_DSR(DST[1][b], xb1 + (BUF) * (4u * kHT), (2 * (I) + b) * 16 * kRowB);    \
-    }
-#define LCM_HRD_W2(BUF, TN0)                                                         \
-    _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                  \
-        LCM_DSR(w[0][TN0 + a], wb0 + (BUF) * (4u * kHT), ((TN0) + a) * 16 * kRowB);  \
-        LCM_DSR(w[1][TN0 + a], wb1 + (BUF) * (4u * kHT), ((TN0) + a) * 16 * kRowB);  \
-    }
-#define LCM_HMMA8(TN0, XF, I)                    \
-    __builtin_amdgcn_s_setprio(1);               \
-    LCM_MMA8(TN0, XF, I)                         \
-    __builtin_amdgcn_s_setprio(0);
-#define LCM_HTILE(BUF, KT, MORE1, MORE2)                                                               \
-    {                                                                                                  \
-        LCM_HRD_X2(xo, BUF, 1)                                                                         \
-        if (MORE1) stage_x(1, (KT) + 1, (BUF) ^ 1);                                                    \
-        LCM_LGKM(8);                                                                                   \
-        LCM_HPIN();                                                                                    \
-        LCM_HMMA8(0, xe, 0)                                                                            \
-        LCM_HPIN();                                                                                    \
-        LCM_LGKM(4);                                                                                   \
-        LCM_HPIN();                                                                                    \
-        LCM_HMMA8(2, xe, 0)                                                                            \
-        LCM_HPIN();                                                                                    \
-        __builtin_amdgcn_s_barrier();                                                                  \
-        LCM_HRD_X2(xe, BUF, 2)                                                                         \
-        if (MORE2) stage_w(0, (KT) + 2, BUF);                                                          \
-        LCM_LGKM(4);                                                                                   \
-        LCM_HPIN();                                                                                    \
-        LCM_HMMA8(0, xo, 1)                                                                            \
-        LCM_HMMA8(2, xo, 1)                                                                            \
-        LCM_HPIN();                                                                                    \
-        LCM_HRD_X2(xo, BUF, 3)                                                                         \
-        if (MORE2) stage_w(1, (KT) + 2, BUF);                                                          \
-        LCM_LGKM(4);                                                                                   \
-        LCM_HPIN();                                                                                    \
-        LCM_HMMA8(0, xe, 2)                                                                            \
-        LCM_HMMA8(2, xe, 2)                                                                            \
-        LCM_HPIN();                                                                                    \
-        if (MORE2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                    \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
-        LCM_LGKM(0);                                                                                   \
-        __builtin_amdgcn_s_barrier();                                                                  \
-        if (MORE2) stage_x(0, (KT) + 2, BUF);                                                          \
-        if (MORE1) { LCM_HRD_X2(xe, (BUF) ^ 1, 0) }                                                    \
-        LCM_HPIN();                                                                                    \
-        LCM_HMMA8(0, xo, 3)                                                                            \
-        LCM_HPIN();                                                                                    \
-        if (MORE1) { LCM_HRD_W2((BUF) ^ 1, 0) }                                                        \
-        LCM_HPIN();                                                                                    \
-        LCM_HMMA8(2, xo, 3)                                                                            \
-        LCM_HPIN();                                                                                    \
-        if (MORE1) { LCM_HRD_W2((BUF) ^ 1, 2) }                                                        \
-    }
-        LCM_HRD_X2(xe, 0, 0)
-        LCM_HRD_W2(0, 0)
-        LCM_HRD_W2(0, 2)
-        for (int kt = 0; kt < nk - 2; kt += 2) {     // nk is even: K is a multiple of 128
-            LCM_HTILE(0, kt, true, true)
-            LCM_HTILE(1, kt + 1, true, true)
-        }
-        LCM_HTILE(0, nk - 2, true, false)
-        LCM_HTILE(1, nk - 1, false, false)
-#undef LCM_HTILE
-#undef LCM_HMMA8
-#undef LCM_HRD_W2
-#undef LCM_HRD_X2
-#undef LCM_HPIN
-#undef LCM_LGKM
-#undef LCM_DSR
-    } else {
     LCM_RD_X2(xe, smem, 0)
     LCM_RD_W2(smem, 0)
-    if constexpr (WT == 4) LCM_RD_W2(smem, 2)
+    LCM_RD_W2(smem, 2)
     // one K tile; MORE1 / MORE2: K tiles kt + 1 / kt + 2 exist (compile-time: the loop body has no branches).
     // hipcc waits for EVERY outstanding LDS read whenever a product needs one, so each phase first issues the half
     // of its products whose operands were read a phase ago, and only then the reads for the next phase.
@@ -574,7 +465,7 @@ __global__ __launch_bounds__(512) void k_gemm_big256(GemmArgs p) {
         const int buf = kt & 1;
         const char* base = smem + buf * (4 * kHT);
         const char* nbase = smem + (buf ^ 1) * (4 * kHT);
-        if constexpr (WT == 4) {
+        {
             // ---- phase 0
             __builtin_amdgcn_s_setprio(1);
             LCM_MMA8(0, xe, 0)
@@ -639,67 +530,6 @@ __global__ __launch_bounds__(512) void k_gemm_big256(GemmArgs p) {
     #pragma unroll
                 for (int a = 0; a < 2; ++a) { w[0][a] = wn[0][a]; w[1][a] = wn[1][a]; }
             }
-        } else {
-            // ---- the 256 x 128 tile: the same four phases with one weight half-tile and 2 x 4 products per phase
-            __builtin_amdgcn_s_setprio(1);
-            LCM_MMA4(xe, 0, 0)
-            __builtin_amdgcn_s_setprio(0);
-            LCM_PIN();
-            LCM_RD_X2(xo, base, 1)
-            if constexpr (more1) stage_x(1, kt + 1, buf ^ 1);
-            LCM_PIN();
-            __builtin_amdgcn_s_setprio(1);
-            LCM_MMA4(xe, 0, 1)
-            __builtin_amdgcn_s_setprio(0);
-            // ---- phase 1: barrier A frees the weight half
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_s_setprio(1);
-            LCM_MMA4(xo, 1, 0)
-            __builtin_amdgcn_s_setprio(0);
-            LCM_PIN();
-            LCM_RD_X2(xe, base, 2)
-            if constexpr (more2) stage_w(0, kt + 2, buf);
-            LCM_PIN();
-            __builtin_amdgcn_s_setprio(1);
-            LCM_MMA4(xo, 1, 1)
-            __builtin_amdgcn_s_setprio(0);
-            // ---- phase 2
-            __builtin_amdgcn_s_setprio(1);
-            LCM_MMA4(xe, 2, 0)
-            __builtin_amdgcn_s_setprio(0);
-            LCM_PIN();
-            LCM_RD_X2(xo, base, 3)
-            LCM_PIN();
-            __builtin_amdgcn_s_setprio(1);
-            LCM_MMA4(xe, 2, 1)
-            __builtin_amdgcn_s_setprio(0);
-            // ---- phase 3: K tile kt + 1 has landed (at most the weight half-tile of kt + 2 pending) -> barrier B
-            if constexpr (more2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if constexpr (more2) stage_x(0, kt + 2, buf);   // (both activation halves here, a phase earlier: 2-4 % slower)
-            __builtin_amdgcn_s_setprio(1);
-            LCM_MMA4(xo, 3, 0)
-            __builtin_amdgcn_s_setprio(0);
-            LCM_PIN();
-            bf16x8 wn[2][2];
-            if constexpr (more1) {
-                LCM_RD_X2(xe, nbase, 0)
-#pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    wn[0][a] = *reinterpret_cast<const bf16x8*>(nbase + w_off + a * 16 * kRowB + slot0);
-                    wn[1][a] = *reinterpret_cast<const bf16x8*>(nbase + w_off + a * 16 * kRowB + slot1);
-                }
-            }
-            LCM_PIN();
-            __builtin_amdgcn_s_setprio(1);
-            LCM_MMA4(xo, 3, 1)
-            __builtin_amdgcn_s_setprio(0);
-            if constexpr (more1) {
-#pragma unroll
-                for (int a = 0; a < 2; ++a) { w[0][a] = wn[0][a]; w[1][a] = wn[1][a]; }
-            }
         }
     };
     using yes = std::true_type;
@@ -707,24 +537,22 @@ __global__ __launch_bounds__(512) void k_gemm_big256(GemmArgs p) {
     for (int kt = 0; kt < nk - 2; ++kt) tile(kt, yes{}, yes{});
     tile(nk - 2, yes{}, no{});
     tile(nk - 1, no{}, no{});
-    }
 #undef LCM_PIN
 #undef LCM_RD_W2
 #undef LCM_RD_X2
 #undef LCM_MMA8
-#undef LCM_MMA4
 
-    constexpr int NC = big_wave_cols<EPI, WT>();
+    constexpr int NC = big_wave_cols<EPI, 4>();
     const int n_wave0 = DUAL ? bx * 128 + wc * 32 : bx * BNW + wc * 16 * WT;
     float4 res0[big_resid_rounds<EPI, NC>()];
     big_load_resid<EPI, NC>(p, m0 + wr * 128, n_wave0, 0, lane, res0);
-    big_epilogue<bf16_t, EPI, 8, WT>(p, acc, smem, wid, m0 + wr * 128, n_wave0, 0, lane, res0);
+    big_epilogue<bf16_t, EPI, 8, 4>(p, acc, smem, wid, m0 + wr * 128, n_wave0, 0, lane, res0);
 }
 
 // ------------------------------------------------------------------------------------------------
 // 256 (activation rows) x 128 (weight rows) tile, 8 waves as 4 (activation rows) x 2 (weight rows): a wave owns 64 x 64
-// outputs = 4 x 4 accumulator tiles, so a K tile costs it 8 + 8 fragment reads for 32 products (the 128 x 32 wave tile
-// of k_gemm_big256<EPI, 2> needs 16 + 4).  Staging, swizzle, buffers, barriers and hazards are those of k_gemm_big256:
+// outputs = 4 x 4 accumulator tiles, so a K tile costs it 8 + 8 fragment reads for 32 products (a 128 x 32 wave tile
+// would need 16 + 4).  Staging, swizzle, buffers, barriers and hazards are those of k_gemm_big256:
 // two K tiles of [activation half 0][activation half 1][weight half] in LDS, four phases of 8 products (activation tile
 // i of the wave x its 4 weight tiles x both k-steps), barrier A before phase 1 frees the weight half, the counted wait
 // + barrier B in phase 3 publish K tile kt + 1 and free the activation halves.  The weight fragments of tile kt + 1
@@ -925,12 +753,11 @@ __global__ __launch_bounds__(512) void k_gemm_big256x128(GemmArgs p) {
 // K splits for the split-K (slab) form: two workgroups per CU (512; with one per CU a workgroup's four waves have
 // nothing to overlap their barriers with: at 1024 rows ffn_out 46.8 -> 31.6 us, self_ov 22.4 -> 18.3 us, end to end
 // +8 % at 512 documents; 768 and 1024 measured slower again), at least 8 K tiles per split (4: slower), and the splits
-// divide the K tiles.  LCMHIP_BIG_SPLIT_TARGET / LCMHIP_BIG_MIN_KT override both.
+// divide the K tiles.
 int gemm_big_splits(const GemmArgs& a, int max_splits) {
     const int tiles = (a.N / kBN) * ((a.M + kBM - 1) / kBM);   // counted in 128-row tiles
     const int nk = a.K / 64;
-    static const int target = [] { const char* e = getenv("LCMHIP_BIG_SPLIT_TARGET"); return e ? atoi(e) : 512; }();
-    static const int min_kt = [] { const char* e = getenv("LCMHIP_BIG_MIN_KT"); return e ? atoi(e) : 8; }();
+    constexpr int target = 512, min_kt = 8;
     int s = 1;
     while (tiles * s < target && nk % (s * 2) == 0 && nk / (s * 2) >= min_kt && s * 2 <= (max_splits > 0 ? max_splits : 64)) s *= 2;
     return s;
@@ -941,16 +768,15 @@ int gemm_big_splits(const GemmArgs& a, int max_splits) {
 // rows the denoiser's ffn_out takes 16.5 against 19.3 us, the sampling loop at 128 documents runs 3.7 % faster; at
 // 384 rows the 128 x 128 kernel wins by 7 %).
 bool gemm_big_applicable(const GemmArgs& a, bool may_split) {
-    static const int min_rows = [] { const char* e = getenv("LCMHIP_BIG_MIN_ROWS"); return e ? atoi(e) : 384; }();
+    constexpr int min_rows = 384;
     const int wrows = (a.epilogue == LCMHIP_EPI_SWIGLU ? 2 * a.N : a.N) * std::max(1, a.stack);
     if (a.stack > 1 && a.N % kBN != 0) return false;
     if (!(a.dtype == LCMHIP_BF16 && a.M >= min_rows && a.K % 64 == 0 && wrows % kBN == 0 && a.lda % 8 == 0)) return false;
     const int tiles = (wrows / kBN) * ((a.M + kBM - 1) / kBM);
     const int s = may_split ? gemm_big_splits(a, a.max_splits) : 1;
     // a product that needs a K split to fill the chip must reach 320 workgroups (a d x d product at 512 rows has 256:
-    // 12.8 us on the LDS-DMA tile against 15.6 us here), an unsplit one 192 (LCMHIP_BIG_MIN_WG overrides both)
-    static const int min_wg = [] { const char* e = getenv("LCMHIP_BIG_MIN_WG"); return e ? atoi(e) : 0; }();
-    return tiles * s >= (min_wg > 0 ? min_wg : (s > 1 ? 320 : 192));
+    // 12.8 us on the LDS-DMA tile against 15.6 us here), an unsplit one 192
+    return tiles * s >= (s > 1 ? 320 : 192);
 }
 
 // epi: LCMHIP_EPI_* or EPI_PARTIAL; splits >= 1 (only with EPI_PARTIAL); m_rows: rows the row tiles must cover
@@ -958,25 +784,21 @@ bool gemm_big_applicable(const GemmArgs& a, bool may_split) {
 // for its waves of tiles.  A full wave of 256 x 256 tiles takes about 1.6 x a full wave of 128 x 128 tiles (measured
 // on the SwiGLU projection: 50-56 us against 32-34 us; four times the work at 1.15-1.2 x the rate), and a partly
 // filled last wave takes as long as a full one: at 1024 rows 176 tiles in one wave take 56 us against 67 us for 704
-// tiles of 128 x 128 in two.  The ratio differs between devices of the pool (see below).  No K split, 32-bit operand offsets.  LCMHIP_BIG256_MIN_TILES > 0 replaces the estimate
-// by a plain tile count.
+// tiles of 128 x 128 in two.  The ratio differs between devices of the pool (see below).  No K split, 32-bit operand
+// offsets.  LCMHIP_BIG256=0 (read at every launch: tests compare the kernels inside one process) turns the kernel off.
 static bool big256_applicable(const GemmArgs& a, int epi, int splits, int m_rows) {
-    static const int mode = [] { const char* e = getenv("LCMHIP_BIG256"); return e ? atoi(e) : 1; }();
-    static const int min_tiles = [] { const char* e = getenv("LCMHIP_BIG256_MIN_TILES"); return e ? atoi(e) : 0; }();
-    if (mode == 0 || splits != 1 || epi == EPI_PARTIAL) return false;
+    const char* e = getenv("LCMHIP_BIG256");
+    if ((e && atoi(e) == 0) || splits != 1 || epi == EPI_PARTIAL) return false;
     if (a.N % 256 != 0 && a.stack > 1) return false;
     const int wrows = (epi == LCMHIP_EPI_SWIGLU ? 2 * a.N : a.N) * std::max(1, a.stack);
     if (wrows % 256 != 0 || a.K % 64 != 0 || a.K < 128) return false;
     if ((size_t)a.M * a.lda * 2 >= (1ull << 31) || (size_t)wrows * a.K * 2 >= (1ull << 31)) return false;
     const int tiles = (wrows / 256) * ((m_rows + 255) / 256);
-    if (min_tiles > 0) return tiles >= min_tiles;
     const int tiles128 = (wrows / kBN) * ((m_rows + kBM - 1) / kBM);
     const int waves256 = (tiles + 255) / 256, waves128 = (tiles128 + 511) / 512;
-    // wave-time ratio in tenths (LCMHIP_BIG256_RATIO overrides): the stacked q / k / v product of 4096 rows (384 tiles
-    // in 2 waves against 1536 in 3) measured 2 % faster at 1.3 on a slower device of the pool: too little to move the
-    // routing the batch sweep was tuned with
-    static const int ratio10 = [] { const char* e = getenv("LCMHIP_BIG256_RATIO"); return e ? atoi(e) : 16; }();
-    return ratio10 * waves256 < 10 * waves128;
+    // wave-time ratio 1.6 (the stacked q / k / v product of 4096 rows, 384 tiles in 2 waves against 1536 in 3, measured
+    // 2 % faster at 1.3 on a slower device of the pool: too little to move the routing the batch sweep was tuned with)
+    return 16 * waves256 < 10 * waves128;
 }
 
 // The 256 x 128 tile for linear products without a K split that the 256 x 256 kernel does not take: it replaces the
@@ -995,72 +817,39 @@ static bool big256n128_applicable(const GemmArgs& a, int epi, int splits, int m_
     return true;
 }
 
+// wt = 4: the 256 x 256 tile kernel; wt = 2: the 256 x 128 tile kernel (linear epilogues only)
 static int launch_gemm_big256(const GemmArgs& a_in, int epi, int m_rows, int wt, hipStream_t st) {
     const int wrows = (epi == LCMHIP_EPI_SWIGLU ? 2 * a_in.N : a_in.N) * std::max(1, a_in.stack);
     GemmArgs a = a_in;
     a.tiles_x = wrows / (64 * wt);
     a.tiles_y = (m_rows + 255) / 256;
     dim3 grid(a.tiles_x * a.tiles_y), block(512);
-#define LCM_BIG256_3(E, W, H)                                                                                      \
+#define LCM_BIG256(K, E)                                                                                           \
     {                                                                                                              \
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_big256<E, W, H>), \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&K<E>),                   \
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, kBig256Lds); \
         LCM_HIP_CHECK(attr);                                                                                       \
-        hipLaunchKernelGGL((k_gemm_big256<E, W, H>), grid, block, kBig256Lds, st, a);                              \
+        hipLaunchKernelGGL((K<E>), grid, block, kBig256Lds, st, a);                                                \
     }
-#define LCM_BIG256(E, W) LCM_BIG256_3(E, W, false)
-    const char* he = getenv("LCMHIP_BIG256_HR");      // hand-issued fragment reads (read per call); needs K % 128 == 0
-    const bool hr = (he ? atoi(he) != 0 : false) && a.K % 128 == 0;
-    if (wt == 4 && hr) {
+    if (wt == 4) {
         switch (epi) {
-            case LCMHIP_EPI_STORE: LCM_BIG256_3(LCMHIP_EPI_STORE, 4, true); break;
-            case LCMHIP_EPI_STORE_F32: LCM_BIG256_3(LCMHIP_EPI_STORE_F32, 4, true); break;
-            case LCMHIP_EPI_RELU: LCM_BIG256_3(LCMHIP_EPI_RELU, 4, true); break;
-            case LCMHIP_EPI_SWIGLU: LCM_BIG256_3(LCMHIP_EPI_SWIGLU, 4, true); break;
-            case LCMHIP_EPI_RESID: LCM_BIG256_3(LCMHIP_EPI_RESID, 4, true); break;
-            default: return fail(LCMHIP_ERR_INVALID, "gemm: unknown epilogue");
-        }
-    } else if (wt == 4) {
-        switch (epi) {
-            case LCMHIP_EPI_STORE: LCM_BIG256(LCMHIP_EPI_STORE, 4); break;
-            case LCMHIP_EPI_STORE_F32: LCM_BIG256(LCMHIP_EPI_STORE_F32, 4); break;
-            case LCMHIP_EPI_RELU: LCM_BIG256(LCMHIP_EPI_RELU, 4); break;
-            case LCMHIP_EPI_SWIGLU: LCM_BIG256(LCMHIP_EPI_SWIGLU, 4); break;
-            case LCMHIP_EPI_RESID: LCM_BIG256(LCMHIP_EPI_RESID, 4); break;
+            case LCMHIP_EPI_STORE: LCM_BIG256(k_gemm_big256, LCMHIP_EPI_STORE); break;
+            case LCMHIP_EPI_STORE_F32: LCM_BIG256(k_gemm_big256, LCMHIP_EPI_STORE_F32); break;
+            case LCMHIP_EPI_RELU: LCM_BIG256(k_gemm_big256, LCMHIP_EPI_RELU); break;
+            case LCMHIP_EPI_SWIGLU: LCM_BIG256(k_gemm_big256, LCMHIP_EPI_SWIGLU); break;
+            case LCMHIP_EPI_RESID: LCM_BIG256(k_gemm_big256, LCMHIP_EPI_RESID); break;
             default: return fail(LCMHIP_ERR_INVALID, "gemm: unknown epilogue");
         }
     } else {
-        // wave layout of the 256 x 128 tile: 4 x 2 waves of 64 x 64 (default) or, LCMHIP_BIG256_N128_LAYOUT=1, 2 x 4 of 128 x 32
-        const char* le = getenv("LCMHIP_BIG256_N128_LAYOUT");   // read per call, like the mode
-        const int layout = le ? atoi(le) : 0;
-#define LCM_BIG256X128(E)                                                                                              \
-    {                                                                                                                  \
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_big256x128<E>),       \
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kBig256Lds);    \
-        LCM_HIP_CHECK(attr);                                                                                           \
-        hipLaunchKernelGGL((k_gemm_big256x128<E>), grid, block, kBig256Lds, st, a);                                    \
-    }
-        if (layout == 1) {
-            switch (epi) {
-                case LCMHIP_EPI_STORE: LCM_BIG256(LCMHIP_EPI_STORE, 2); break;
-                case LCMHIP_EPI_STORE_F32: LCM_BIG256(LCMHIP_EPI_STORE_F32, 2); break;
-                case LCMHIP_EPI_RELU: LCM_BIG256(LCMHIP_EPI_RELU, 2); break;
-                case LCMHIP_EPI_RESID: LCM_BIG256(LCMHIP_EPI_RESID, 2); break;
-                default: return fail(LCMHIP_ERR_INVALID, "gemm: the 256 x 128 tile takes linear epilogues only");
-            }
-        } else {
-            switch (epi) {
-                case LCMHIP_EPI_STORE: LCM_BIG256X128(LCMHIP_EPI_STORE); break;
-                case LCMHIP_EPI_STORE_F32: LCM_BIG256X128(LCMHIP_EPI_STORE_F32); break;
-                case LCMHIP_EPI_RELU: LCM_BIG256X128(LCMHIP_EPI_RELU); break;
-                case LCMHIP_EPI_RESID: LCM_BIG256X128(LCMHIP_EPI_RESID); break;
-                default: return fail(LCMHIP_ERR_INVALID, "gemm: the 256 x 128 tile takes linear epilogues only");
-            }
+        switch (epi) {
+            case LCMHIP_EPI_STORE: LCM_BIG256(k_gemm_big256x128, LCMHIP_EPI_STORE); break;
+            case LCMHIP_EPI_STORE_F32: LCM_BIG256(k_gemm_big256x128, LCMHIP_EPI_STORE_F32); break;
+            case LCMHIP_EPI_RELU: LCM_BIG256(k_gemm_big256x128, LCMHIP_EPI_RELU); break;
+            case LCMHIP_EPI_RESID: LCM_BIG256(k_gemm_big256x128, LCMHIP_EPI_RESID); break;
+            default: return fail(LCMHIP_ERR_INVALID, "gemm: the 256 x 128 tile takes linear epilogues only");
         }
-#undef LCM_BIG256X128
     }
 #undef LCM_BIG256
-#undef LCM_BIG256_3
     LCM_HIP_CHECK(hipGetLastError());
     return LCMHIP_OK;
 }

@@ -90,12 +90,6 @@ def ab_env(var, on, shapes, label_off, label_on, iters=50):
         print(f"M={M} N={N} K={K} epi={epi}: {label_off} {a:7.1f} us ({fl / a / 1e6:6.0f} TF), {label_on} {b:7.1f} us ({fl / b / 1e6:6.0f} TF)  ({100 * (a / b - 1):+.1f} %)", flush=True)
     os.environ.pop(var, None)
 
-if os.environ.get("GB_AB_HR"):
-    ab_env("LCMHIP_BIG256_HR", "1", [(4096, 5632, 2048, _hip.EPI_SWIGLU), (1024, 5632, 2048, _hip.EPI_SWIGLU), (4096, 4096, 4096, _hip.EPI_STORE),
-                                     (2304, 6400, 2048, _hip.EPI_STORE), (4096, 4096, 2048, _hip.EPI_RESID), (8192, 8192, 8192, _hip.EPI_STORE)],
-           "compiler-issued reads", "hand-issued reads", iters=20)
-    sys.exit(0)
-
 if os.environ.get("GB_AB_N128"):
     pr = torch.cuda.get_device_properties(0)
     print(f"device: {pr.name}, {pr.multi_processor_count} CUs, clock {getattr(pr, 'clock_rate', 0) / 1e3:.0f} MHz, "

@@ -28,8 +28,8 @@ for it in range(rounds):
     outs = []
     with torch.cuda.stream(side):
         noise_b.copy_(noise_a, non_blocking=True)
-    for mode, layout in (("0", "0"), ("1", "0"), ("1", "1")):
-        os.environ["LCMHIP_BIG256_N128"], os.environ["LCMHIP_BIG256_N128_LAYOUT"] = mode, layout
+    for mode in ("0", "1"):
+        os.environ["LCMHIP_BIG256_N128"] = mode
         out = res0.clone() if f32 else torch.empty(M, N, device=dev, dtype=torch.bfloat16)
         _hip.check(_hip.lib.lcmhip_gemm(_hip.ptr(A), K, _hip.ptr(W), None, _hip.ptr(b), None, None, _hip.ptr(out), N, M, N, K, epi,
                                         _hip.BF16, None, 0, st))

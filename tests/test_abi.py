@@ -79,3 +79,28 @@ def test_model_table_validation_without_gpu(hip):
     den.pos_kind = 2
     desc.denoiser = den
     assert hip.lib.lcmhip_model_create(C.byref(desc), C.byref(handle)) == -3
+
+
+def test_library_override_and_version_gate(tmp_path):
+    """LCMHIP_LIB loads another build of the same ABI; a path that does not exist is an ImportError, never a silent
+    fallback to the default library (or to anything on the CPU)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import lcm._hip as h; print(h.LIB_PATH, h.lib.lcmhip_version())"
+    copy = tmp_path / "liblcm_other_build.so"
+    copy.write_bytes(open(os.path.join(root, "chimera-llm_amd", "lcm", "liblcm_hip.so"), "rb").read())
+    env = dict(os.environ, LCMHIP_LIB=str(copy), PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split()[0] == str(copy) and int(out.stdout.split()[1]) == 300
+    env["LCMHIP_LIB"] = str(tmp_path / "missing.so")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "ImportError" in out.stderr
+
+
+def test_unknown_session_flags_are_rejected(hip):
+    handle = C.c_void_p()          # flags are validated before the model is looked at
+    n = C.c_size_t(0)
+    assert hip.lib.lcmhip_session_workspace_bytes(handle, 4, 16, 10, 1 << 9, C.byref(n)) == -1
+    assert b"flag" in hip.lib.lcmhip_last_error()

@@ -117,14 +117,12 @@ def test_gemm_one_tile_per_cu(hip, M, K):
     _check_epilogues(hip, torch.bfloat16, M, 6400, K, False)
 
 
-@pytest.mark.parametrize("layout", ["0", "1"])
 @pytest.mark.parametrize("M,N,K", [(4096, 2048, 2048), (4000, 2048, 768), (3700, 6144, 256), (513, 1280, 5632)])
-def test_gemm_256x128_tile(hip, monkeypatch, M, N, K, layout):
-    """The 256 x 128 tile kernels (the default routing of linear many-row products without a K split; layout 0: wave tile 64 x 64 with hand-issued fragment reads and
-    counted waits, layout 1: wave tile 128 x 32) against float64 through every linear epilogue, and bit for bit against
-    the 128 x 128 kernel (LCMHIP_BIG256_N128=0): every output sums its K tiles in the same order in all of these kernels.  Ragged row counts,
-    the shortest K loop the interface allows (4 K tiles), several waves of tiles."""
-    import os
+def test_gemm_256x128_tile(hip, monkeypatch, M, N, K):
+    """The 256 x 128 tile kernel (the default routing of linear many-row products without a K split: wave tile 64 x 64,
+    hand-issued fragment reads with counted waits) against float64 through every linear epilogue, and bit for bit
+    against the 128 x 128 kernel (LCMHIP_BIG256_N128=0): every output sums its K tiles in the same order in both
+    kernels.  Ragged row counts, the shortest K loop the interface allows (4 K tiles), several waves of tiles."""
     dt = torch.bfloat16
     torch.manual_seed(M + N + K)
     A = torch.randn(M, K).cuda().to(dt)
@@ -151,7 +149,6 @@ def test_gemm_256x128_tile(hip, monkeypatch, M, N, K, layout):
     monkeypatch.setenv("LCMHIP_BIG256_N128", "0")
     base = run_all()
     monkeypatch.setenv("LCMHIP_BIG256_N128", "1")
-    monkeypatch.setenv("LCMHIP_BIG256_N128_LAYOUT", layout)
     got = run_all()
     lin = A.double().cpu() @ W.double().cpu().T
     ref = lin + b.double().cpu()
@@ -161,6 +158,47 @@ def test_gemm_256x128_tile(hip, monkeypatch, M, N, K, layout):
     assert (got[3].double().cpu() - (res0.double().cpu() + gate.double().cpu() * ref)).abs().max() <= 2e-3 * max(1.0, float((gate.double().cpu() * ref).abs().max()))
     for g, o in zip(got, base):
         assert torch.equal(g, o)
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(4096, 5632, 2048, "swiglu"), (1024, 5632, 2048, "swiglu"), (2600, 4096, 512, "store"),
+                                         (4096, 4096, 1024, "resid")])
+def test_gemm_256x256_tile(hip, monkeypatch, M, N, K, epi):
+    """The 256 x 256 tile kernel (one workgroup per CU; taken where its waves of tiles finish first: the SwiGLU
+    up-projection of many rows, large square products) bit for bit against the 128 x 128 kernel that LCMHIP_BIG256=0 and
+    LCMHIP_BIG256_N128=0 route the same call to (the same K order per output), and against float64."""
+    dt = torch.bfloat16
+    torch.manual_seed(M + N + K)
+    A = torch.randn(M, K).cuda().to(dt)
+    W = (torch.randn(N, K) / math.sqrt(K)).cuda().to(dt)
+    W2 = (torch.randn(N, K) / math.sqrt(K)).cuda().to(dt) if epi == "swiglu" else None
+    b = torch.randn(N).cuda().to(dt)
+    b2 = torch.randn(N).cuda().to(dt) if epi == "swiglu" else None
+    gate = torch.randn(N).cuda() if epi == "resid" else None
+    res0 = torch.randn(M, N).cuda()
+    code = {"swiglu": hip.EPI_SWIGLU, "store": hip.EPI_STORE, "resid": hip.EPI_RESID}[epi]
+
+    def run():
+        o = res0.clone() if epi == "resid" else torch.empty(M, N, device="cuda", dtype=dt)
+        _gemm(hip, A, W, W2, b, b2, gate, o, code)
+        torch.cuda.synchronize()
+        return o
+
+    monkeypatch.setenv("LCMHIP_BIG256", "0")
+    monkeypatch.setenv("LCMHIP_BIG256_N128", "0")
+    base = run()
+    monkeypatch.delenv("LCMHIP_BIG256")
+    monkeypatch.delenv("LCMHIP_BIG256_N128")
+    got = run()
+    assert torch.equal(got, base)
+    lin = A.double().cpu() @ W.double().cpu().T + b.double().cpu()
+    if epi == "swiglu":
+        ref = (A.double().cpu() @ W2.double().cpu().T + b2.double().cpu()) * torch.nn.functional.silu(lin)
+    elif epi == "resid":
+        ref = res0.double().cpu() + gate.double().cpu() * lin
+    else:
+        ref = lin
+    tol = 2e-3 if epi == "resid" else 3e-2
+    assert (got.double().cpu() - ref).abs().max() <= tol * max(1.0, float(ref.abs().max()))
 
 
 @pytest.mark.parametrize("M", [65, 96, 128])
