@@ -29,6 +29,11 @@ struct Profiler {
     bool enabled = false;
     std::vector<Pair> pairs;      // pairs recorded since the last collect
     std::vector<Pair> free_pairs;
+    // At most this many pairs are outstanding: begin() drains the stream and collects when the limit is reached.
+    // Unbounded, a profiled pass of a long run holds tens of thousands of live HIP events; rocprofv3 in counter
+    // collection mode (--pmc) died with a host-side SIGSEGV inside its dispatch interception at about 4000 profiled
+    // launches (512 documents x 496 prompt positions; 128 documents x 100 steps alike), whatever kernel came next.
+    static constexpr size_t kMaxPairs = 1024;
     std::vector<Row> rows;
     std::map<std::string, int> index;
 
@@ -46,6 +51,7 @@ struct Profiler {
         rows[r].launches += 1;
         rows[r].bytes += bytes;
         rows[r].flops += flops;
+        if (pairs.size() >= kMaxPairs && hipStreamSynchronize(st) == hipSuccess) collect();
         Pair p;
         if (!free_pairs.empty()) {
             p = free_pairs.back();
