@@ -174,6 +174,24 @@ struct ProfScope {
 constexpr int kMaxSplits = 12;
 
 // ---- kernel launchers (implemented in the .hip files) ---------------------------------------------
+// Inner activation of the two-matrix FFN (LCMHIP_ACT_*): torch.nn.ReLU / Tanh / ELU / LeakyReLU / SELU / GELU (erf
+// form) / SiLU / Softsign / Sigmoid / Hardsigmoid with their default arguments, evaluated in fp32.  `kind` is
+// uniform over a launch.
+__device__ __forceinline__ float apply_act(float v, int kind) {
+    switch (kind) {
+        case LCMHIP_ACT_TANH: return tanhf(v);
+        case LCMHIP_ACT_ELU: return v > 0.f ? v : expm1f(v);
+        case LCMHIP_ACT_LEAKY_RELU: return v > 0.f ? v : 0.01f * v;
+        case LCMHIP_ACT_SELU: return 1.0507009873554804934193349852946f * (v > 0.f ? v : 1.6732632423543772848170429916717f * expm1f(v));
+        case LCMHIP_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        case LCMHIP_ACT_SILU: return v / (1.f + __expf(-v));
+        case LCMHIP_ACT_SOFTSIGN: return v / (1.f + fabsf(v));
+        case LCMHIP_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+        case LCMHIP_ACT_HARDSIGMOID: return fminf(fmaxf(v * (1.f / 6.f) + 0.5f, 0.f), 1.f);
+        default: return fmaxf(v, 0.f);
+    }
+}
+
 struct GemmArgs {
     const void* A; int lda;
     const void* W; const void* W2;
@@ -188,6 +206,7 @@ struct GemmArgs {
     int out_head_cap;
     int M, N, K;
     int epilogue;
+    int act;                    // LCMHIP_ACT_* of the LCMHIP_EPI_RELU epilogue (0 = ReLU)
     int dtype;
     // RESID only: rows [M, M + extra_rows) of `out` get gate[n] * extra_const[n] added
     int extra_rows; const float* extra_const;

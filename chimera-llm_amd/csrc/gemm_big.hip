@@ -116,7 +116,7 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& p, const f32x4 (&ac
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     v[r] = acc[tn][tm][r] + bv[tn][r];
-                    if constexpr (EPI == LCMHIP_EPI_RELU) v[r] = fmaxf(v[r], 0.f);
+                    if constexpr (EPI == LCMHIP_EPI_RELU) v[r] = apply_act(v[r], p.act);
                     if constexpr (DUAL) {
                         const float g = v[r];
                         v[r] = (acc[tn + TNW / 2][tm][r] + bv2[tn][r]) * (g / (1.f + __expf(-g)));

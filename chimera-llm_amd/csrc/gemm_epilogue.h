@@ -86,7 +86,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x4 (&a
                     if (m >= p.M) continue;
                     if constexpr (EPI == LCMHIP_EPI_RELU) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                        for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
                     }
                     if constexpr (DUAL) {
 #pragma unroll

@@ -58,7 +58,10 @@ extern "C" int lcmhip_gemm_static(const void* A, int32_t lda, const void* W, con
     LCM_TRY(scratch_for_current_device(&ws));
     GemmArgs a{};
     a.A = A; a.lda = lda; a.W = W; a.W2 = W2; a.bias = bias; a.bias2 = bias2; a.gate = gate;
-    a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.epilogue = epilogue; a.dtype = dtype;
+    a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.epilogue = epilogue & 0xff; a.dtype = dtype;
+    a.act = (epilogue >> 8) & 0xff;
+    LCM_REQUIRE((epilogue >> 16) == 0 && a.act <= LCMHIP_ACT_HARDSIGMOID && (a.act == 0 || a.epilogue == LCMHIP_EPI_RELU),
+                "gemm_static: an activation code goes with LCMHIP_EPI_RELU only");
     a.partial = static_cast<float*>(ws); a.partial_bytes = LCMHIP_STATIC_SCRATCH_BYTES; a.max_splits = kMaxSplits;
     return launch_gemm(a, static_cast<hipStream_t>(stream));
 }

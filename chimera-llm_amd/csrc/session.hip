@@ -194,6 +194,7 @@ static int check_tower(const lcmhip_tower_desc& t, int d, const char* which) {
     LCM_REQUIRE(t.ffn_dim % 128 == 0, std::string(which) + ": ffn_dim must be a multiple of 128");
     LCM_REQUIRE(t.norm_kind >= LCMHIP_NORM_LAYERNORM && t.norm_kind <= LCMHIP_NORM_UNIT, "unknown norm kind");
     LCM_REQUIRE(t.ffn_kind == LCMHIP_FFN_RELU || t.ffn_kind == LCMHIP_FFN_SWIGLU, "unknown ffn kind");
+    LCM_REQUIRE(t.ffn_activation >= LCMHIP_ACT_RELU && t.ffn_activation <= LCMHIP_ACT_HARDSIGMOID, "unknown ffn activation");
     return LCMHIP_OK;
 }
 
@@ -463,9 +464,10 @@ static void gemm_cost(const GemmArgs& a, double out_es, double* bytes, double* f
 static int gemm(lcmhip_session* s, const char* tag, const void* A, int lda, const Lin& W, const Lin* W2,
                 const float* gate, void* out, int ldo, int M, int epi, hipStream_t st,
                 const int32_t* out_rows = nullptr, int extra_rows = 0, const float* extra_const = nullptr,
-                int out_head_cap = 0, const RowSteps* gate_steps = nullptr) {
+                int out_head_cap = 0, const RowSteps* gate_steps = nullptr, int act = LCMHIP_ACT_RELU) {
     GemmArgs a = gemm_args(s, A, lda, W, W2, M, epi);
     a.gate = gate;
+    a.act = act;
     if (gate_steps && gate_steps->row_step) {
         a.gate_rows = gate_steps->row_step; a.gate_stride = gate_steps->step_stride; a.gate_steps = gate_steps->n_steps;
     }
@@ -588,7 +590,8 @@ static int ffn_in(lcmhip_session* s, const char* tag, const lcmhip_tower_desc& t
     const int d = s->model->desc.model_dim;
     if (t.ffn_kind == LCMHIP_FFN_SWIGLU)
         return gemm(s, tag, a, d, f.gate, &f.inner, nullptr, s->act_h, t.ffn_dim, rows, LCMHIP_EPI_SWIGLU, st);
-    return gemm(s, tag, a, d, f.inner, nullptr, nullptr, s->act_h, t.ffn_dim, rows, LCMHIP_EPI_RELU, st);
+    return gemm(s, tag, a, d, f.inner, nullptr, nullptr, s->act_h, t.ffn_dim, rows, LCMHIP_EPI_RELU, st, nullptr, 0, nullptr, 0,
+                nullptr, t.ffn_activation);
 }
 
 }  // namespace lcmhip
@@ -1414,7 +1417,10 @@ int lcmhip_gemm(const void* A, int32_t lda, const void* W, const void* W2, const
     LCM_REQUIRE(A && W && out, "gemm: null argument");
     GemmArgs a{};
     a.A = A; a.lda = lda; a.W = W; a.W2 = W2; a.bias = bias; a.bias2 = bias2; a.gate = gate;
-    a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.epilogue = epilogue; a.dtype = dtype;
+    a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.epilogue = epilogue & 0xff; a.dtype = dtype;
+    a.act = (epilogue >> 8) & 0xff;      // LCMHIP_EPI_RELU | (LCMHIP_ACT_x << 8)
+    LCM_REQUIRE((epilogue >> 16) == 0 && a.act <= LCMHIP_ACT_HARDSIGMOID && (a.act == 0 || a.epilogue == LCMHIP_EPI_RELU),
+                "gemm: an activation code goes with LCMHIP_EPI_RELU only");
     a.partial = splitk_ws; a.partial_bytes = splitk_ws_bytes; a.max_splits = kMaxSplits;
     return launch_gemm(a, static_cast<hipStream_t>(stream));
 }

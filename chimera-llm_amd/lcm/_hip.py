@@ -17,6 +17,9 @@ LIB_PATH = os.environ.get("LCMHIP_LIB") or os.path.join(_HERE, "liblcm_hip.so")
 F32, BF16 = 0, 1
 NORM_LAYERNORM, NORM_RMS, NORM_FP32, NORM_UNIT = 0, 1, 2, 3
 FFN_RELU, FFN_SWIGLU = 0, 1
+# LCMHIP_ACT_*: inner activation of the two-matrix FFN, by the reference's name (lcm/nn/initialization.py:121-151)
+ACT = {"relu": 0, "tanh": 1, "elu": 2, "leaky_relu": 3, "selu": 4, "gelu": 5, "silu": 6, "softsign": 7, "sigmoid": 8,
+       "hardsigmoid": 9}
 POS_NONE, POS_LEARNED, POS_ROPE = 0, 1, 2
 PRED = {"sample": 0, "epsilon": 1, "v_prediction": 2}
 EPI_STORE, EPI_STORE_F32, EPI_RELU, EPI_SWIGLU, EPI_RESID = 0, 1, 2, 3, 4
@@ -42,7 +45,8 @@ EXPORTS = [
 class TowerDesc(C.Structure):
     _fields_ = [("num_layers", C.c_int32), ("num_heads", C.c_int32), ("ffn_dim", C.c_int32),
                 ("norm_kind", C.c_int32), ("ffn_kind", C.c_int32), ("pos_kind", C.c_int32),
-                ("out_proj_bias", C.c_int32), ("rope_theta", C.c_float), ("qk_layernorm", C.c_int32)]
+                ("out_proj_bias", C.c_int32), ("rope_theta", C.c_float), ("qk_layernorm", C.c_int32),
+                ("ffn_activation", C.c_int32)]
 
 
 class ModelDesc(C.Structure):

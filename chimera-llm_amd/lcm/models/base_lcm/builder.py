@@ -16,6 +16,7 @@ import torch
 from torch import Tensor
 
 from lcm import _hip
+from lcm.nn.weight_norm import fold_weight_norm
 from lcm.datasets.batch import EmbeddingsBatch
 from lcm.models.abstract_lcm import AbstractLCModel, AbstractLCModelConfig
 from lcm.models.sonar_normalizer.builder import SonarNormalizer, SonarNormalizerConfig
@@ -132,8 +133,8 @@ class BaseLCModel(AbstractLCModel):
         _check_supported("lcm", config.lcm)
         if config.model_output_dim not in (None, config.sonar_embed_dim):
             raise NotImplementedError("model_output_dim other than the SONAR dimension is not implemented on the HIP path")
-        if config.postnet.activation_name is not None or config.postnet.weight_normalization or config.frontend.weight_normalization:
-            raise NotImplementedError("postnet activation / weight normalization are not implemented on the HIP path")
+        if config.postnet.activation_name is not None:
+            raise NotImplementedError("a postnet activation is not implemented on the HIP path")
         self.model_dim = config.model_dim
         self.sonar_embed_dim = config.sonar_embed_dim
         ncfg = normalizer_config_for(config.sonar_normalizer_name, config.sonar_embed_dim)
@@ -175,6 +176,7 @@ class BaseLCModel(AbstractLCModel):
 
     def load_state_dict(self, state_dict: Dict[str, Tensor], strict: bool = True) -> None:
         sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+        sd = fold_weight_norm(sd)      # weight-normalized projections of a checkpoint become plain matrices
         missing = [k for k in self._params if k not in sd]
         unexpected = [k for k in sd if k not in self._params]
         if strict and (missing or unexpected):
@@ -195,7 +197,8 @@ class BaseLCModel(AbstractLCModel):
             norm_kind=_NORM_KIND[tc.layer_normalization_style],
             ffn_kind=_hip.FFN_SWIGLU if tc.use_swiglu else _hip.FFN_RELU,
             pos_kind=_POS_KIND[tc.pos_embedding_style], out_proj_bias=int(tc.mha_output_proj_bias),
-            rope_theta=float(tc.rope_theta), qk_layernorm=int(tc.enable_qk_layernorm))
+            rope_theta=float(tc.rope_theta), qk_layernorm=int(tc.enable_qk_layernorm),
+                ffn_activation=_hip.ACT.get(tc.ffn_inner_activation_name, 0))
         none = _hip.TowerDesc(num_layers=0)      # no denoiser tower: selects the base LCM in the library
         desc = _hip.ModelDesc(sonar_dim=c.sonar_embed_dim, model_dim=c.model_dim, max_seq_len=c.max_seq_len,
                               timestep_freq_dim=TIMESTEP_FREQ_DIM, dtype=_hip.dtype_code(self.dtype), norm_eps=1e-5,

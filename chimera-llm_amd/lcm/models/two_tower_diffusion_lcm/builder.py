@@ -17,6 +17,7 @@ import torch
 from torch import Tensor
 
 from lcm import _hip
+from lcm.nn.weight_norm import fold_weight_norm
 from lcm.datasets.batch import EmbeddingsBatch
 from lcm.models.abstract_lcm import AbstractLCModel, AbstractLCModelConfig
 from lcm.models.sonar_normalizer.builder import SonarNormalizer, SonarNormalizerConfig
@@ -70,11 +71,10 @@ def _check_supported(name: str, tc: TransformerConfig) -> None:
         bad.append("only pre-norm stacks")
     if tc.pos_embedding_style not in _POS_KIND:
         bad.append(f"pos_embedding_style={tc.pos_embedding_style}")
-    if tc.mha_qkv_weight_normalization or tc.mha_output_weight_normalization:
-        bad.append("weight-norm parametrization of the attention projections")
     if tc.scale_residual is not None:
         bad.append("scale_residual")
-    if not tc.use_swiglu and tc.ffn_inner_activation_name != "relu":
+    if not tc.use_swiglu and tc.ffn_inner_activation_name not in _hip.ACT:
+        # "prelu" carries a learned slope (a parameter of the activation module); anything else is unknown to the reference too
         bad.append(f"ffn activation {tc.ffn_inner_activation_name}")
     if bad:
         raise NotImplementedError(f"{name}: not implemented on the HIP path: {', '.join(bad)}")
@@ -452,6 +452,7 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
 
     def load_state_dict(self, state_dict: Dict[str, Tensor], strict: bool = True) -> None:
         sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+        sd = fold_weight_norm(sd)      # weight-normalized projections of a checkpoint become plain matrices
         missing = [k for k in self._params if k not in sd]
         unexpected = [k for k in sd if k not in self._params]
         if strict and (missing or unexpected):
@@ -475,7 +476,8 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
                 norm_kind=_NORM_KIND[tc.layer_normalization_style],
                 ffn_kind=_hip.FFN_SWIGLU if tc.use_swiglu else _hip.FFN_RELU,
                 pos_kind=_POS_KIND[tc.pos_embedding_style], out_proj_bias=int(tc.mha_output_proj_bias),
-                rope_theta=float(tc.rope_theta), qk_layernorm=int(tc.enable_qk_layernorm))
+                rope_theta=float(tc.rope_theta), qk_layernorm=int(tc.enable_qk_layernorm),
+                ffn_activation=_hip.ACT.get(tc.ffn_inner_activation_name, 0))
 
         desc = _hip.ModelDesc(sonar_dim=c.sonar_embed_dim, model_dim=c.model_dim, max_seq_len=c.max_seq_len,
                               timestep_freq_dim=TIMESTEP_FREQ_DIM, dtype=_hip.dtype_code(self.dtype), norm_eps=1e-5,

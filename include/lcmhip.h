@@ -29,7 +29,7 @@ extern "C" {
 
 /* Version of this ABI (struct layouts and signatures).  lcmhip_version() returns the value the library was built
  * with; a caller built against another value must not bind.  200 -> 300: lcmhip_session_workspace_bytes and
- * lcmhip_session_create take `flags`, lcmhip_static_init added; 100 -> 200: lcmhip_tower_desc.qk_layernorm,
+ * lcmhip_session_create take `flags`, lcmhip_static_init added, lcmhip_tower_desc.ffn_activation; 100 -> 200: lcmhip_tower_desc.qk_layernorm,
  * thresholding fields of lcmhip_denoise_params, variance_noise of lcmhip_ddim_cfg_step. */
 #define LCMHIP_ABI_VERSION 300
 
@@ -44,7 +44,13 @@ enum { LCMHIP_F32 = 0, LCMHIP_BF16 = 1 };
  * (LayerNorm evaluated in fp32, weight only) and "unit" (LayerNorm without learnable parameters).  Every kind keeps
  * its statistics in fp32 here, so "fp32" differs from "standard" only by the missing bias. */
 enum { LCMHIP_NORM_LAYERNORM = 0, LCMHIP_NORM_RMS = 1, LCMHIP_NORM_FP32 = 2, LCMHIP_NORM_UNIT = 3 };
-enum { LCMHIP_FFN_RELU = 0, LCMHIP_FFN_SWIGLU = 1 };
+enum { LCMHIP_FFN_RELU = 0, LCMHIP_FFN_SWIGLU = 1 };  /* FFN_RELU: the two-matrix FFN with the activation of ffn_activation */
+/* Inner activation of the two-matrix FFN (lcm/nn/transformer/factory.py:73, lcm/nn/initialization.py:121-151: the
+ * torch.nn modules of these names with their default arguments).  "prelu" has a learned slope and is not offered. */
+enum {
+    LCMHIP_ACT_RELU = 0, LCMHIP_ACT_TANH = 1, LCMHIP_ACT_ELU = 2, LCMHIP_ACT_LEAKY_RELU = 3, LCMHIP_ACT_SELU = 4,
+    LCMHIP_ACT_GELU = 5, LCMHIP_ACT_SILU = 6, LCMHIP_ACT_SOFTSIGN = 7, LCMHIP_ACT_SIGMOID = 8, LCMHIP_ACT_HARDSIGMOID = 9
+};
 enum { LCMHIP_POS_NONE = 0, LCMHIP_POS_LEARNED = 1, LCMHIP_POS_ROPE = 2 };
 enum { LCMHIP_PRED_SAMPLE = 0, LCMHIP_PRED_EPSILON = 1, LCMHIP_PRED_V = 2 };
 
@@ -52,7 +58,8 @@ enum { LCMHIP_PRED_SAMPLE = 0, LCMHIP_PRED_EPSILON = 1, LCMHIP_PRED_V = 2 };
 enum {
     LCMHIP_EPI_STORE = 0,     /* out[m][n] = acc + bias[n]            (out in the operand dtype) */
     LCMHIP_EPI_STORE_F32 = 1, /* same, fp32 output                                               */
-    LCMHIP_EPI_RELU = 2,      /* out = max(acc + bias, 0)                                        */
+    LCMHIP_EPI_RELU = 2,      /* out = act(acc + bias); act = ReLU, or LCMHIP_ACT_x when the epilogue
+                                 argument is LCMHIP_EPI_RELU | (LCMHIP_ACT_x << 8)                */
     LCMHIP_EPI_SWIGLU = 3,    /* out = (acc2 + bias2) * silu(acc + bias); W = gate, W2 = inner   */
     LCMHIP_EPI_RESID = 4      /* resid[m][n] += gate[n] * (acc + bias[n]); fp32, gate optional   */
 };
@@ -73,6 +80,7 @@ typedef struct {
     int32_t qk_layernorm;  /* 0 / 1: LayerNorm (the tower's norm style, full model_dim) on q and on k after their
                               projections, before the head split and RoPE; lcm/nn/transformer/attention.py:143-199.
                               Tensors <attn>.q_layer_norm.* and <attn>.k_layer_norm.* */
+    int32_t ffn_activation; /* LCMHIP_ACT_*: inner activation when ffn_kind == LCMHIP_FFN_RELU (0 = ReLU) */
 } lcmhip_tower_desc;
 
 /* lcm/models/two_tower_diffusion_lcm/builder.py:49-81 (TwoTowerDiffusionLCModelConfig). */

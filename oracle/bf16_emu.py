@@ -38,7 +38,7 @@ import torch.nn.functional as F
 from torch import Tensor
 
 from .archs import TowerConfig
-from .model import KVCache, OracleBaseLCM, OracleTwoTower, causal_mask, rope
+from .model import ACTIVATIONS, KVCache, OracleBaseLCM, OracleTwoTower, causal_mask, rope
 
 PREFILL_MIN = 4      # shortest causal query block that takes the matrix-core prefill kernel
 PREFILL_TILE = 32    # keys per tile of that kernel
@@ -179,7 +179,7 @@ class _Bf16Blocks:
         if tc.use_swiglu:
             act = r16(_lin(h, sd, prefix + ".inner_proj") * _silu(_lin(h, sd, prefix + ".gate_proj")))
         else:
-            act = r16(F.relu(_lin(h, sd, prefix + ".inner_proj")))
+            act = r16(ACTIVATIONS[tc.activation](_lin(h, sd, prefix + ".inner_proj")))
         return _lin(act, sd, prefix + ".output_proj")
 
     def _stack(self, x_norm16: Tensor, cache: Optional[KVCache], frontend: str, decoder: str, tc: TowerConfig,

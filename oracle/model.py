@@ -25,6 +25,14 @@ from .scheduler import DDIMSchedule
 
 # ----------------------------------------------------------------------------- primitives
 
+# lcm/nn/initialization.py:121-151 (parse_activation_fn): the torch.nn modules of these names with default arguments,
+# the inner activation of the two-matrix FFN (transformer/factory.py:289-300).  "prelu" (a learned slope) is left out.
+ACTIVATIONS = {
+    "relu": torch.nn.ReLU(), "tanh": torch.nn.Tanh(), "elu": torch.nn.ELU(), "leaky_relu": torch.nn.LeakyReLU(),
+    "selu": torch.nn.SELU(), "gelu": torch.nn.GELU(), "silu": torch.nn.SiLU(), "softsign": torch.nn.Softsign(),
+    "sigmoid": torch.nn.Sigmoid(), "hardsigmoid": torch.nn.Hardsigmoid(),
+}
+
 def linear(x: Tensor, sd: Dict[str, Tensor], prefix: str) -> Tensor:
     return F.linear(x, sd[prefix + ".weight"], sd.get(prefix + ".bias"))
 
@@ -197,8 +205,7 @@ class OracleTwoTower:
         if tc.use_swiglu:   # fairseq2 GLUFeedForwardNetwork: output(inner(x) * silu(gate(x)))
             return linear(linear(x, sd, prefix + ".inner_proj") * F.silu(linear(x, sd, prefix + ".gate_proj")),
                           sd, prefix + ".output_proj")
-        assert tc.activation == "relu"
-        return linear(F.relu(linear(x, sd, prefix + ".inner_proj")), sd, prefix + ".output_proj")
+        return linear(ACTIVATIONS[tc.activation](linear(x, sd, prefix + ".inner_proj")), sd, prefix + ".output_proj")
 
     # -- contextualizer (builder.py:161-191)
     def encode(self, x_norm: Tensor, cache: Optional[KVCache] = None, *, frontend: str = "encoder_frontend",

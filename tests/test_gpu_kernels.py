@@ -545,3 +545,38 @@ def test_ddim_cfg_step_many_rows(hip, mode, dim):
     hip.check(hip.lib.lcmhip_ddim_cfg_step(hip.ptr(xg), hip.ptr(ocg), hip.ptr(oug) if mode == "cfg" else None, hip.ptr(p3),
                                            hip.ptr(z3), 5, dim, float(a_t), float(a_prev), C.byref(p), hip.ptr(vng), _st(hip)))
     assert (p3 - pg[:5]).abs().max() <= 1e-5
+
+
+_ACT_MODULES = {"relu": torch.nn.ReLU(), "tanh": torch.nn.Tanh(), "elu": torch.nn.ELU(), "leaky_relu": torch.nn.LeakyReLU(),
+                "selu": torch.nn.SELU(), "gelu": torch.nn.GELU(), "silu": torch.nn.SiLU(), "softsign": torch.nn.Softsign(),
+                "sigmoid": torch.nn.Sigmoid(), "hardsigmoid": torch.nn.Hardsigmoid()}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", sorted(_ACT_MODULES))
+def test_gemm_activation_epilogues(hip, dtype, act):
+    """out = act(A W^T + b) for every inner activation the reference's two-matrix FFN can name
+    (lcm/nn/initialization.py:121-151), against the torch module of that name on a float64 product.  Shapes take the
+    call through the weight-streaming tiles (50 rows, with and without a K split + finishing pass) and, in bf16, the
+    many-row matrix-core kernels (2048 and 4096 rows)."""
+    code = hip.EPI_RELU | (hip.ACT[act] << 8)
+    shapes = [(50, 1024, 512, False), (50, 1024, 2048, True)]
+    if dtype == torch.bfloat16:
+        shapes += [(2048, 2048, 512, False), (4096, 4096, 256, False)]
+    for M, N, K, split in shapes:
+        torch.manual_seed(M + N + K)
+        A = torch.randn(M, K).cuda().to(dtype)
+        W = (1.5 * torch.randn(N, K) / math.sqrt(K)).cuda().to(dtype)       # pre-activations of both signs, |v| up to ~5
+        b = torch.randn(N).cuda().to(dtype)
+        out = torch.empty(M, N, device="cuda", dtype=dtype)
+        ws = torch.empty(16 * M * N, device="cuda") if split else None
+        _gemm(hip, A, W, None, b, None, None, out, code, ws)
+        torch.cuda.synchronize()
+        ref = _ACT_MODULES[act](A.double().cpu() @ W.double().cpu().T + b.double().cpu())
+        tol = 2e-5 if dtype == torch.float32 else 1.2e-2
+        err = (out.double().cpu() - ref).abs().max()
+        assert err <= tol * max(1.0, float(ref.abs().max())), (act, M, N, K, float(err))
+    # an activation code on any other epilogue is refused
+    rc = hip.lib.lcmhip_gemm(hip.ptr(A), K, hip.ptr(W), None, None, None, None, hip.ptr(out), N, M, N, K,
+                             hip.EPI_STORE | (hip.ACT["gelu"] << 8), hip.dtype_code(dtype), None, 0, _st(hip))
+    assert rc == -1

@@ -302,3 +302,61 @@ def test_encode_without_a_state_bag():
     got = model.encode(EmbeddingsBatch(xn.cuda(), None)).seqs.float().cpu()
     assert got.shape == want.shape
     assert (got - want).abs().max() <= 1e-3 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("act", ["gelu", "silu", "tanh"])
+def test_ffn_inner_activation(act):
+    """`ffn_inner_activation_name` of the two-matrix FFN (reference lcm/nn/transformer/factory.py:73, 289-300) in
+    both towers of the toy arch (the arch whose FFN is not SwiGLU): generation against the oracle, fp32."""
+    arch = "toy_two_tower_diffusion_lcm"
+    from lcm.models.two_tower_diffusion_lcm import create_two_tower_diffusion_lcm_model, lcm_archs
+    cfg, sd, x, nz = make_problem(arch, 3, 3, 2)
+    cfg.context.activation = cfg.denoiser.activation = act
+    opts = dict(DEFAULT_OPTS, inference_timesteps=6)
+    ref = run_oracle(cfg, sd, x, nz, 2, opts)
+    mc = lcm_archs.get_config(arch)
+    mc.context_encoder.ffn_inner_activation_name = mc.denoiser.ffn_inner_activation_name = act
+    model = create_two_tower_diffusion_lcm_model(mc, device="cuda:0", dtype=torch.float32)
+    model.load_state_dict(sd)
+    out, _ = run_hip(arch, sd, x, nz, 2, opts, model=model)
+    worst, cos = compare(out.hypotheses, ref, sd, start=3)
+    assert worst <= 1e-3 and cos >= 0.9999, (act, worst, cos)
+    relu = run_oracle(O.get_arch(arch), sd, x, nz, 2, opts)
+    assert compare(out.hypotheses, relu, sd, start=3)[0] > 1e-2          # the activation is really in the path
+    mc.denoiser.ffn_inner_activation_name = "prelu"
+    with pytest.raises(NotImplementedError):
+        create_two_tower_diffusion_lcm_model(mc, device="cuda:0", dtype=torch.float32)
+
+
+def test_weight_normalized_checkpoint():
+    """A checkpoint whose attention projections were wrapped in weight normalization (reference
+    `mha_qkv_weight_normalization` / `mha_output_weight_normalization`: attention.py:123-127, factory.py:253-254) holds
+    (g, v) pairs instead of `weight`; loading folds them.  The model loaded from such a state dict equals the oracle
+    run on the explicit g * v / ||v|| matrices."""
+    arch = "mini_two_tower_diffusion_lcm"
+    cfg, sd, x, nz = make_problem(arch, 3, 3, 2)
+    opts = dict(DEFAULT_OPTS, inference_timesteps=6)
+    g = torch.Generator().manual_seed(5)
+    wn_sd, folded = {}, {}
+    for k, v in sd.items():
+        is_attn_proj = k.endswith((".q_proj.weight", ".k_proj.weight", ".v_proj.weight", ".output_proj.weight")) and "attn" in k + "attention"
+        if is_attn_proj and ".ffn." not in k:
+            mag = v.norm(dim=1, keepdim=True) * (0.5 + torch.rand(v.shape[0], 1, generator=g))      # g != ||v||: a real rescale
+            direction = v * (0.3 + torch.rand(v.shape[0], 1, generator=g))                            # any positive row scale of v
+            wn_sd[k[:-len("weight")] + "parametrizations.weight.original0"] = mag
+            wn_sd[k[:-len("weight")] + "parametrizations.weight.original1"] = direction
+            folded[k] = direction * (mag / direction.norm(dim=1, keepdim=True))
+        else:
+            wn_sd[k] = v
+            folded[k] = v
+    assert len(wn_sd) > len(sd)
+    ref = run_oracle(cfg, folded, x, nz, 2, opts)
+    mc = mini_config()
+    mc.context_encoder.mha_qkv_weight_normalization = mc.denoiser.mha_qkv_weight_normalization = True
+    mc.context_encoder.mha_output_weight_normalization = mc.denoiser.mha_output_weight_normalization = True
+    from lcm.models.two_tower_diffusion_lcm import create_two_tower_diffusion_lcm_model
+    model = create_two_tower_diffusion_lcm_model(mc, device="cuda:0", dtype=torch.float32)
+    model.load_state_dict(wn_sd)
+    out, _ = run_hip(arch, sd, x, nz, 2, opts, model=model)
+    worst, cos = compare(out.hypotheses, ref, sd, start=3)
+    assert worst <= 1e-3 and cos >= 0.9999, (worst, cos)

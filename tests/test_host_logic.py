@@ -179,3 +179,29 @@ def test_qk_layernorm_adds_its_norms_to_the_parameter_table():
     obase = oracle.get_base_arch("mini_base_lcm")
     obase.lcm.qk_layernorm = True
     assert {n for n, _, _ in base_parameter_spec(bcfg)} == {n for n, _, _ in base_state_dict_spec(obase)}
+
+
+def test_fold_weight_norm_matches_torch_parametrization():
+    """`fold_weight_norm` against the module torch builds: new (`parametrizations.weight.original0/1`) and deprecated
+    (`weight_g` / `weight_v`) names, other entries untouched, a magnitude without its direction refused."""
+    import warnings
+    from lcm.nn.weight_norm import fold_weight_norm
+    torch.manual_seed(0)
+    lin = torch.nn.utils.parametrizations.weight_norm(torch.nn.Linear(24, 10))
+    with torch.no_grad():
+        lin.parametrizations.weight.original0.mul_(torch.rand(10, 1) + 0.5)
+    sd = {"blk.q_proj." + k: v.detach() for k, v in lin.state_dict().items()}
+    sd["blk.other.weight"] = torch.randn(3, 3)
+    out = fold_weight_norm(sd)
+    assert set(out) == {"blk.q_proj.weight", "blk.q_proj.bias", "blk.other.weight"}
+    assert torch.allclose(out["blk.q_proj.weight"], lin.weight.detach(), atol=1e-7)
+    assert out["blk.other.weight"] is sd["blk.other.weight"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        old = torch.nn.utils.weight_norm(torch.nn.Linear(24, 10))
+    sd_old = {"p." + k: v.detach() for k, v in old.state_dict().items()}
+    assert "p.weight_g" in sd_old
+    assert torch.allclose(fold_weight_norm(sd_old)["p.weight"], old.weight.detach(), atol=1e-7)
+    bad = {"m.parametrizations.weight.original0": torch.ones(4, 1)}
+    with pytest.raises(RuntimeError):
+        fold_weight_norm(bad)
