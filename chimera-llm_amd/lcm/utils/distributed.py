@@ -40,6 +40,11 @@ def all_gather_generations(seqs: Tensor, lengths: Tensor, group=None, width: Opt
     agree on it with one more (8-byte) all-reduce."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return seqs, lengths
+    return _gather_packed(seqs, lengths, group, width)
+
+
+def _gather_packed(seqs: Tensor, lengths: Tensor, group=None, width: Optional[int] = None) -> Tuple[Tensor, Tensor]:
+    """The exchange itself (any world size, one rank included): pack, one all-gather, unpack."""
     world = dist.get_world_size(group)
     n_loc = seqs.shape[0]
     if width is None:

@@ -469,3 +469,39 @@ def test_teacher_forced_scorer():
         assert [h[0].seq.shape[0] for h in out.hypotheses] == [n - mcl for n in lens]
         worst, cos = compare(out.hypotheses, ref, sd)
         assert worst <= FP32_MAX_ABS and cos >= FP32_COS, (mcl, worst, cos)
+
+
+def test_packed_all_gather_through_rccl_single_rank():
+    """The output exchange of `bench.py --gpus N` on device tensors through the `nccl` backend (RCCL): a one-rank
+    process group on cuda:0 in a child process runs the same pack -> all_gather_into_tensor -> unpack path that N ranks
+    run (with one rank RCCL's all-gather is a device copy, but backend set-up, the uint8 payload and the unpacking are
+    the real ones).  More ranks need more GPUs than a test box has; the world-size-2 exchange is covered on gloo."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import os, torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ["PORT"], RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+from lcm.utils.distributed import _gather_packed, all_gather_generations
+seqs = torch.randn(5, 9, 1024, device="cuda").bfloat16()
+lens = torch.tensor([9, 3, 7, 9, 1], device="cuda", dtype=torch.int32)
+for width in (5, 8, None):
+    out, olens = _gather_packed(seqs, lens, None, width)
+    torch.cuda.synchronize()
+    assert out.dtype == seqs.dtype and torch.equal(out, seqs) and torch.equal(olens, lens), width
+same, _ = all_gather_generations(seqs, lens)      # one rank: nothing to exchange
+assert same is seqs
+dist.barrier()
+dist.destroy_process_group()
+print("rccl exchange ok")
+"""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PORT=str(port), PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0 and "rccl exchange ok" in out.stdout, out.stderr[-3000:]
