@@ -1,4 +1,4 @@
-"""Summarises the two rocprofv3 --pmc passes written by scripts/profile_r<N>.sh (FETCH_SIZE, WRITE_SIZE; one pass each)
+"""Summarises the two rocprofv3 --pmc passes written by scripts/profile_bench.sh <tag> (FETCH_SIZE, WRITE_SIZE; one pass each)
 into profiles/r<N>_pmc_hbm_traffic.json (usage: pmc_summary.py r2), and copies the kernel-trace statistics and the bench line measured under the
 profiler next to it.  gfx950 correction: FETCH_SIZE counts a 128-byte read request as 64 bytes, so it is doubled;
 WRITE_SIZE is exact; both counters are in KB."""
