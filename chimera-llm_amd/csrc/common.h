@@ -192,6 +192,22 @@ __device__ __forceinline__ float apply_act(float v, int kind) {
     }
 }
 
+// Write-through stores (sc1: the line goes to memory at device scope as it is written instead of staying dirty in the
+// XCD's L2 until the write-back at the kernel's end).  For the short kernels of the sampling loop, whose outputs the
+// next kernel reads from all 8 XCDs anyway, that shortens every kernel boundary behind a split-K product: with the
+// slab stores of the K < 4096 products and both stores of the pending-product norm written through, config
+// two_tower_diffusion 1.6B, 64 documents: 1389 -> 1424 sentence-embeddings/s (self_ov 10.35 -> 9.69 us, cross_o 7.66 ->
+// 7.21, cross_q 7.34 -> 7.00 per launch); 8 / 16 / 32 / 128 / 256 documents +0.4 / 1.3 / 2.0 / 1.9 / 2.3 %.  Not for
+// the K = 5632 slabs (12.8 -> 13.6 us at 64 documents), the SwiGLU / attention / q outputs (no change) or with the
+// non-temporal bit (nt, alone or with sc1: slower norm).
+typedef float st_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16_through(void* dst, st_f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store8_through(void* dst, uint64_t v) {
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+}
+
 struct GemmArgs {
     const void* A; int lda;
     const void* W; const void* W2;
@@ -225,6 +241,7 @@ struct GemmArgs {
     int scatter_mask, rope_mask;
     const int32_t* rope_pos; const float* rope_cos; const float* rope_sin;
     int stack_sel;              // set by the kernels: the matrix of the workgroup's tile
+    int slab_through;           // set by the launcher: split-K slab stores are written through (store16_through)
 };
 // True when launch_gemm would run this stacked product as ONE launch of a many-row kernel (whose epilogue knows the
 // per-matrix switches above); otherwise it runs one product per matrix and the switches must not be set.

@@ -387,7 +387,7 @@ __global__ __launch_bounds__(NT) void k_norm_pending(float* __restrict__ x, cons
     float v[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] += a[j];
-    *reinterpret_cast<float4*>(xr) = make_float4(v[0], v[1], v[2], v[3]);
+    store16_through(xr, st_f32x4{v[0], v[1], v[2], v[3]});   // both stores written through: see store16_through
     if (row >= rows_norm) return;   // uniform per workgroup
     // ---- statistics
     float mean = 0.f, rstd;
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(NT) void k_norm_pending(float* __restrict__ x, cons
         uint2 pk;
         pk.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
         pk.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
-        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(yr)) = pk;
+        store8_through(yr, (uint64_t)pk.x | ((uint64_t)pk.y << 32));
     }
 }
 

@@ -503,7 +503,9 @@ static int launch_cfg(const GemmArgs& a, const Plan& pl, int epi, hipStream_t st
 }
 
 template <typename T>
-static int launch_plan(const GemmArgs& a, const Plan& pl, int epi, hipStream_t st) {
+static int launch_plan(const GemmArgs& a0, const Plan& pl, int epi, hipStream_t st) {
+    GemmArgs a = a0;
+    a.slab_through = epi == EPI_PARTIAL && a.K < 4096;   // see store16_through
     if (pl.wm == 1) return launch_cfg<T, 1, 4, 4>(a, pl, epi, st);
     if (pl.wm == 4 && pl.wn == 2) {
         if (std::is_same<T, bf16_t>::value) return launch_dma<4>(a, pl, epi, st);

@@ -28,9 +28,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x4 (&a
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
                 const int m = m_wave0 + tm * 16 + (lane & 15);
-                if (m < p.M)
-                    *reinterpret_cast<float4*>(slab + (size_t)m * p.N + n) =
-                        make_float4(acc[tn][tm][0], acc[tn][tm][1], acc[tn][tm][2], acc[tn][tm][3]);
+                if (m >= p.M) continue;
+                float* dst = slab + (size_t)m * p.N + n;
+                if (p.slab_through) store16_through(dst, acc[tn][tm]);
+                else *reinterpret_cast<f32x4*>(dst) = acc[tn][tm];
             }
         }
     } else {
