@@ -351,6 +351,12 @@ int launch_rope_store(void* q, const void* k, const void* v, void* kc, void* vc,
                       const int32_t* positions, const float* cos_tab, const float* sin_tab, int rows, int d,
                       int cap, int use_rope, int dtype, hipStream_t st);
 int launch_add_pos(float* x, const void* table, const int32_t* positions, int rows, int d, int dtype, hipStream_t st);
+// x[r][:] += the sinusoidal encoding of positions[r] (first half sines, second half cosines; LCMHIP_POS_SINE)
+int launch_add_sine_pos(float* x, const int32_t* positions, int rows, int d, hipStream_t st);
+// Helpers of the post-norm / normformer layer orders and of scale_residual (n = rows * d elements, d % 8 == 0):
+int launch_cast_rows(const float* x, void* y, int64_t n, int dtype, hipStream_t st);                 // y = T(x)
+int launch_take_rows(float* x, const void* y, int64_t n, int dtype, int accumulate, hipStream_t st);  // x = float(y) or x += float(y)
+int launch_scale_cols(float* x, const void* scale, int rows, int d, int dtype, hipStream_t st);      // x[r][c] *= scale[c]
 int launch_fill_rows(void* cache, const void* vec, const int32_t* rows_idx, int n_rows, int d, int cap, int dtype,
                      hipStream_t st);
 // Element offset of column n of mapped row r (= slot * cap + position) in a [slot][head][position][128] cache.

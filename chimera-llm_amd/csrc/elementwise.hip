@@ -1322,6 +1322,97 @@ int launch_add_pos(float* x, const void* table, const int32_t* positions, int ro
     return LCMHIP_OK;
 }
 
+// fairseq2 SinusoidalPositionEncoder as the reference's frontend uses it (lcm/nn/transformer/factory.py:199-204): the
+// table is built in fp32 -- outer(position, exp(-i ln(10000) / (h - 1))), sin of it in the first h = d / 2 columns, cos
+// in the last h -- and added to the sequence in fp32.  Computed on the fly here (one exp and one sin / cos per element).
+__global__ __launch_bounds__(256) void k_add_sine_pos(float* __restrict__ x, const int32_t* __restrict__ positions, int d) {
+    const int r = blockIdx.x, h = d / 2;
+    const float pos = (float)positions[r];
+    const float step = -9.210340371976184f / (float)(h - 1);   // -ln(10000) / (h - 1)
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
+        const int i = c < h ? c : c - h;
+        const float a = pos * expf((float)i * step);
+        x[(size_t)r * d + c] += c < h ? sinf(a) : cosf(a);
+    }
+}
+
+int launch_add_sine_pos(float* x, const int32_t* positions, int rows, int d, hipStream_t st) {
+    LCM_REQUIRE(d % 2 == 0 && d >= 4, "pos: the sinusoidal encoding needs an even dim");
+    if (rows <= 0) return LCMHIP_OK;
+    hipLaunchKernelGGL(k_add_sine_pos, dim3(rows), dim3(256), 0, st, x, positions, d);
+    LCM_HIP_CHECK(hipGetLastError());
+    return LCMHIP_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_cast_rows(const float* __restrict__ x, T* __restrict__ y, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        float a[8];
+        load8<float>(x + i * 8, a);
+        store8<T>(y + i * 8, a);
+    }
+}
+template <typename T, bool ACC>
+__global__ __launch_bounds__(256) void k_take_rows(float* __restrict__ x, const T* __restrict__ y, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        float a[8], b[8];
+        load8<T>(y + i * 8, b);
+        if (ACC) {
+            load8<float>(x + i * 8, a);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) b[j] += a[j];
+        }
+        store8<float>(x + i * 8, b);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_scale_cols(float* __restrict__ x, const T* __restrict__ scale, int d) {
+    const int r = blockIdx.x;
+    for (int c = threadIdx.x * 8; c < d; c += blockDim.x * 8) {
+        float a[8], b[8];
+        load8<float>(x + (size_t)r * d + c, a);
+        load8<T>(scale + c, b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] *= b[j];
+        store8<float>(x + (size_t)r * d + c, a);
+    }
+}
+
+static inline unsigned flat_grid(int64_t n8) { return (unsigned)std::min<int64_t>(8192, (n8 + 255) / 256); }
+
+int launch_cast_rows(const float* x, void* y, int64_t n, int dtype, hipStream_t st) {
+    LCM_REQUIRE(n % 8 == 0, "cast: element count must be a multiple of 8");
+    if (n <= 0) return LCMHIP_OK;
+    if (dtype == LCMHIP_BF16) hipLaunchKernelGGL((k_cast_rows<bf16_t>), dim3(flat_grid(n / 8)), dim3(256), 0, st, x, (bf16_t*)y, n / 8);
+    else hipLaunchKernelGGL((k_cast_rows<float>), dim3(flat_grid(n / 8)), dim3(256), 0, st, x, (float*)y, n / 8);
+    LCM_HIP_CHECK(hipGetLastError());
+    return LCMHIP_OK;
+}
+
+int launch_take_rows(float* x, const void* y, int64_t n, int dtype, int accumulate, hipStream_t st) {
+    LCM_REQUIRE(n % 8 == 0, "take: element count must be a multiple of 8");
+    if (n <= 0) return LCMHIP_OK;
+    const dim3 grid(flat_grid(n / 8)), block(256);
+    if (dtype == LCMHIP_BF16) {
+        if (accumulate) hipLaunchKernelGGL((k_take_rows<bf16_t, true>), grid, block, 0, st, x, (const bf16_t*)y, n / 8);
+        else hipLaunchKernelGGL((k_take_rows<bf16_t, false>), grid, block, 0, st, x, (const bf16_t*)y, n / 8);
+    } else {
+        if (accumulate) hipLaunchKernelGGL((k_take_rows<float, true>), grid, block, 0, st, x, (const float*)y, n / 8);
+        else hipLaunchKernelGGL((k_take_rows<float, false>), grid, block, 0, st, x, (const float*)y, n / 8);
+    }
+    LCM_HIP_CHECK(hipGetLastError());
+    return LCMHIP_OK;
+}
+
+int launch_scale_cols(float* x, const void* scale, int rows, int d, int dtype, hipStream_t st) {
+    LCM_REQUIRE(d % 8 == 0, "scale: dim must be a multiple of 8");
+    if (rows <= 0) return LCMHIP_OK;
+    if (dtype == LCMHIP_BF16) hipLaunchKernelGGL((k_scale_cols<bf16_t>), dim3(rows), dim3(256), 0, st, x, (const bf16_t*)scale, d);
+    else hipLaunchKernelGGL((k_scale_cols<float>), dim3(rows), dim3(256), 0, st, x, (const float*)scale, d);
+    LCM_HIP_CHECK(hipGetLastError());
+    return LCMHIP_OK;
+}
+
 // cache[rows_idx[i]][:] = vec[:]   (vec null: zeros)
 template <typename T>
 __global__ __launch_bounds__(256) void k_fill_rows(T* __restrict__ cache, const T* __restrict__ vec,

@@ -102,7 +102,13 @@ struct Lin { const void* w = nullptr; const void* b = nullptr; int out = 0, in =
 struct NormW { const void* w = nullptr; const void* b = nullptr; };
 struct AttnW { Lin q, k, v, o; NormW qn, kn; };   // qn / kn: optional q / k LayerNorm (attention.py:143-199)
 struct FfnW { Lin gate, inner, out; };
-struct CtxLayer { NormW sa_norm, ffn_norm; AttnW sa; FfnW ffn; };
+struct CtxLayer {
+    NormW sa_norm, ffn_norm;
+    AttnW sa;
+    FfnW ffn;
+    NormW attn_norm, inner_norm;             // normformer order only: after the attention block / on the FFN's inner activations
+    const void* residual_scale = nullptr;    // scale_residual only
+};
 struct DenLayer { NormW sa_norm, ca_norm, ffn_norm; AttnW sa, ca; FfnW ffn; Lin mod; Lin ov; };   // ov: optional folded output_proj * v_proj
 
 }  // namespace lcmhip
@@ -195,6 +201,9 @@ static int check_tower(const lcmhip_tower_desc& t, int d, const char* which) {
     LCM_REQUIRE(t.norm_kind >= LCMHIP_NORM_LAYERNORM && t.norm_kind <= LCMHIP_NORM_UNIT, "unknown norm kind");
     LCM_REQUIRE(t.ffn_kind == LCMHIP_FFN_RELU || t.ffn_kind == LCMHIP_FFN_SWIGLU, "unknown ffn kind");
     LCM_REQUIRE(t.ffn_activation >= LCMHIP_ACT_RELU && t.ffn_activation <= LCMHIP_ACT_HARDSIGMOID, "unknown ffn activation");
+    LCM_REQUIRE(t.pos_kind >= LCMHIP_POS_NONE && t.pos_kind <= LCMHIP_POS_SINE, "unknown position kind");
+    LCM_REQUIRE(t.norm_order >= LCMHIP_ORDER_PRE && t.norm_order <= LCMHIP_ORDER_NORMFORMER, "unknown norm order");
+    LCM_REQUIRE((t.no_final_norm | 1) == 1 && (t.scale_residual | 1) == 1, std::string(which) + ": no_final_norm / scale_residual are 0 or 1");
     return LCMHIP_OK;
 }
 
@@ -616,6 +625,10 @@ int lcmhip_model_create(const lcmhip_model_desc* desc, lcmhip_model** out) {
         LCM_TRY(check_tower(desc->denoiser, desc->model_dim, "denoiser"));
         if (desc->denoiser.pos_kind != LCMHIP_POS_NONE && desc->denoiser.pos_kind != LCMHIP_POS_LEARNED)
             return fail(LCMHIP_ERR_UNSUPPORTED, "denoiser: only learned positions (or none) are implemented for the latents");
+        // lcm_denoiser.py:441-443 asserts against post-norm; the normformer extras and a residual scale (which
+        // LCMDenoiserTransformerFactory.build_layer, denoisers/factory.py:181-191, never forwards) are not offered
+        if (desc->denoiser.norm_order != LCMHIP_ORDER_PRE || desc->denoiser.no_final_norm || desc->denoiser.scale_residual)
+            return fail(LCMHIP_ERR_UNSUPPORTED, "denoiser: pre-norm layers with a final norm and no residual scale only");
     }
     LCM_REQUIRE(desc->embed_scale >= 0.f, "model_create: embed_scale");
     {
@@ -681,8 +694,17 @@ int lcmhip_model_finalize(lcmhip_model* m) {
         LCM_TRY(get_norm(m, p + ".ffn_layer_norm", dm, d.context.norm_kind, &L.ffn_norm));
         LCM_TRY(get_attn(m, p + ".self_attn", dm, d.context, &L.sa));
         LCM_TRY(get_ffn(m, p + ".ffn", dm, d.context, &L.ffn));
+        if (d.context.norm_order == LCMHIP_ORDER_NORMFORMER) {
+            LCM_TRY(get_norm(m, p + ".self_attn_norm", dm, d.context.norm_kind, &L.attn_norm));
+            // the two-matrix FFN's own LayerNorm is fairseq2's default one (weight + bias) whatever the tower's style:
+            // TransformerFactory.build_ffn (factory.py:292-300) passes the order but no layer-norm factory
+            if (d.context.ffn_kind == LCMHIP_FFN_RELU)
+                LCM_TRY(get_norm(m, p + ".ffn.inner_layer_norm", d.context.ffn_dim, LCMHIP_NORM_LAYERNORM, &L.inner_norm));
+        }
+        if (d.context.scale_residual) LCM_TRY(get_vec(m, p + ".residual_scale", dm, &L.residual_scale));
     }
-    LCM_TRY(get_norm(m, dec + ".layer_norm", dm, d.context.norm_kind, &m->ctx_final));
+    m->ctx_final = NormW{};
+    if (!d.context.no_final_norm) LCM_TRY(get_norm(m, dec + ".layer_norm", dm, d.context.norm_kind, &m->ctx_final));
     m->den.clear();
     if (m->base) {
         LCM_TRY(get_lin(m, "postnet.fc", D, dm, has_tensor(m, "postnet.fc.bias"), &m->postnet));
@@ -1004,9 +1026,20 @@ static int append_impl(lcmhip_session* s, const float* x, int32_t n_tokens, int3
             }
             LCM_TRY(gemm(s, "ctx.frontend", s->act_in, D, m->pre_linear, nullptr, nullptr, s->xres, dm, R, LCMHIP_EPI_STORE_F32, st));
             if (tc.pos_kind == LCMHIP_POS_LEARNED) LCM_TRY(launch_add_pos(s->xres, m->pos_table, s->pos_rows, R, dm, d.dtype, st));
+            if (tc.pos_kind == LCMHIP_POS_SINE) LCM_TRY(launch_add_sine_pos(s->xres, s->pos_rows, R, dm, st));
+            // Layer orders (decoder.py:55-88 for the attention block; the FFN block is fairseq2's
+            // StandardTransformerDecoderLayer._forward_ffn, which alone applies residual_scale):
+            //   pre:        x += attn(norm(x));            x = rs * x + ffn(norm(x))
+            //   post:       x  = norm(x + attn(x));        x = norm(rs * x + ffn(x))
+            //   normformer: x += attn_norm(attn(norm(x))); x = rs * x + ffn'(norm(x))
+            // xres is the fp32 residual stream, act_a the block input in the operand dtype.  After a post-order norm the
+            // stream continues from the normalized rows as the operand dtype holds them (what the reference's stream is).
+            const bool post = tc.norm_order == LCMHIP_ORDER_POST, normformer = tc.norm_order == LCMHIP_ORDER_NORMFORMER;
+            const int64_t n_el = (int64_t)R * dm;
+            if (post) LCM_TRY(launch_cast_rows(s->xres, s->act_a, n_el, d.dtype, st));
             for (int l = 0; l < tc.num_layers; ++l) {
                 const CtxLayer& L = m->ctx[l];
-                LCM_TRY(norm(s, "ctx.norm", s->xres, L.sa_norm, nullptr, nullptr, s->act_a, R, R, tc.norm_kind, nullptr, st));
+                if (!post) LCM_TRY(norm(s, "ctx.norm", s->xres, L.sa_norm, nullptr, nullptr, s->act_a, R, R, tc.norm_kind, nullptr, st));
                 int rc = LCMHIP_OK;
                 if (!tc.qk_layernorm &&
                     qkv_rope_store_fused(s, "ctx.qkv_rope", s->act_a, dm, L.sa, s->act_q, s->self_k + l * self_layer,
@@ -1029,12 +1062,33 @@ static int append_impl(lcmhip_session* s, const float* x, int32_t n_tokens, int3
                     LCM_TRY(launch_attention(s->act_q, s->self_k + l * self_layer, s->self_v + l * self_layer, slots, s->act_o,
                                              n, sc, tc.num_heads, s->cap, pos0, 1, d.dtype, st));
                 }
-                LCM_TRY(gemm(s, "ctx.attn_out", s->act_o, dm, L.sa.o, nullptr, nullptr, s->xres, dm, R, LCMHIP_EPI_RESID, st));
-                LCM_TRY(norm(s, "ctx.norm", s->xres, L.ffn_norm, nullptr, nullptr, s->act_a, R, R, tc.norm_kind, nullptr, st));
+                if (normformer) {
+                    // the block's output passes through its own norm before it joins the stream: project into plain rows
+                    // (act_q is free again), normalize them in place, add
+                    LCM_TRY(gemm(s, "ctx.attn_out", s->act_o, dm, L.sa.o, nullptr, nullptr, s->act_q, dm, R, LCMHIP_EPI_STORE, st));
+                    LCM_TRY(launch_row_norm(s->act_q, L.attn_norm.w ? L.attn_norm.w : s->ones, L.attn_norm.b, nullptr, nullptr, nullptr, R,
+                                            dm, kernel_norm_kind(tc.norm_kind), d.norm_eps, d.dtype, st));
+                    LCM_TRY(launch_take_rows(s->xres, s->act_q, n_el, d.dtype, 1, st));
+                } else {
+                    LCM_TRY(gemm(s, "ctx.attn_out", s->act_o, dm, L.sa.o, nullptr, nullptr, s->xres, dm, R, LCMHIP_EPI_RESID, st));
+                }
+                LCM_TRY(norm(s, "ctx.norm", s->xres, post ? L.sa_norm : L.ffn_norm, nullptr, nullptr, s->act_a, R, R, tc.norm_kind, nullptr, st));
+                if (post) LCM_TRY(launch_take_rows(s->xres, s->act_a, n_el, d.dtype, 0, st));
                 LCM_TRY(ffn_in(s, "ctx.ffn_in", tc, L.ffn, s->act_a, R, st));
+                if (normformer && tc.ffn_kind == LCMHIP_FFN_RELU)
+                    LCM_TRY(launch_row_norm(s->act_h, L.inner_norm.w, L.inner_norm.b, nullptr, nullptr, nullptr, R, tc.ffn_dim,
+                                            LCMHIP_NORM_LAYERNORM, d.norm_eps, d.dtype, st));
+                if (L.residual_scale) LCM_TRY(launch_scale_cols(s->xres, L.residual_scale, R, dm, d.dtype, st));
                 LCM_TRY(gemm(s, "ctx.ffn_out", s->act_h, tc.ffn_dim, L.ffn.out, nullptr, nullptr, s->xres, dm, R, LCMHIP_EPI_RESID, st));
+                if (post) {
+                    LCM_TRY(norm(s, "ctx.norm", s->xres, L.ffn_norm, nullptr, nullptr, s->act_a, R, R, tc.norm_kind, nullptr, st));
+                    LCM_TRY(launch_take_rows(s->xres, s->act_a, n_el, d.dtype, 0, st));
+                }
             }
-            LCM_TRY(norm(s, "ctx.norm", s->xres, m->ctx_final, nullptr, nullptr, s->act_a, R, R, tc.norm_kind, nullptr, st));
+            // the stack's own norm (absent when the final order is "post"); a post-order stack without it ends on the
+            // rows its last layer normalized
+            if (!tc.no_final_norm) LCM_TRY(norm(s, "ctx.norm", s->xres, m->ctx_final, nullptr, nullptr, s->act_a, R, R, tc.norm_kind, nullptr, st));
+            else if (!post) LCM_TRY(launch_cast_rows(s->xres, s->act_a, n_el, d.dtype, st));
             // cross-attention keys / values of the new context positions, every denoiser layer
             for (int l = 0; l < d.denoiser.num_layers; ++l) {
                 const Lin* const w2[2] = {&m->den[l].ca.k, &m->den[l].ca.v};

@@ -20,11 +20,12 @@ FFN_RELU, FFN_SWIGLU = 0, 1
 # LCMHIP_ACT_*: inner activation of the two-matrix FFN, by the reference's name (lcm/nn/initialization.py:121-151)
 ACT = {"relu": 0, "tanh": 1, "elu": 2, "leaky_relu": 3, "selu": 4, "gelu": 5, "silu": 6, "softsign": 7, "sigmoid": 8,
        "hardsigmoid": 9}
-POS_NONE, POS_LEARNED, POS_ROPE = 0, 1, 2
+POS_NONE, POS_LEARNED, POS_ROPE, POS_SINE = 0, 1, 2, 3
+ORDER = {"pre": 0, "post": 1, "normformer": 2}   # LCMHIP_ORDER_*
 PRED = {"sample": 0, "epsilon": 1, "v_prediction": 2}
 EPI_STORE, EPI_STORE_F32, EPI_RELU, EPI_SWIGLU, EPI_RESID = 0, 1, 2, 3, 4
 STATIC_SCRATCH_BYTES = 16 << 20      # LCMHIP_STATIC_SCRATCH_BYTES of include/lcmhip.h
-ABI_VERSION = 300                    # LCMHIP_ABI_VERSION of include/lcmhip.h: the layouts and signatures bound below
+ABI_VERSION = 400                    # LCMHIP_ABI_VERSION of include/lcmhip.h: the layouts and signatures bound below
 # LCMHIP_SESSION_* flags of lcmhip_session_workspace_bytes / lcmhip_session_create
 SESSION_KEEP_CONTEXT, SESSION_SEPARATE_QKV, SESSION_SEPARATE_ROPE, SESSION_NO_GRAPH = 1, 2, 4, 8
 
@@ -46,7 +47,8 @@ class TowerDesc(C.Structure):
     _fields_ = [("num_layers", C.c_int32), ("num_heads", C.c_int32), ("ffn_dim", C.c_int32),
                 ("norm_kind", C.c_int32), ("ffn_kind", C.c_int32), ("pos_kind", C.c_int32),
                 ("out_proj_bias", C.c_int32), ("rope_theta", C.c_float), ("qk_layernorm", C.c_int32),
-                ("ffn_activation", C.c_int32)]
+                ("ffn_activation", C.c_int32), ("norm_order", C.c_int32), ("no_final_norm", C.c_int32),
+                ("scale_residual", C.c_int32)]
 
 
 class ModelDesc(C.Structure):

@@ -21,14 +21,15 @@ from lcm.datasets.batch import EmbeddingsBatch
 from lcm.models.abstract_lcm import AbstractLCModel, AbstractLCModelConfig
 from lcm.models.sonar_normalizer.builder import SonarNormalizer, SonarNormalizerConfig
 from lcm.models.two_tower_diffusion_lcm.builder import (
-    _NORM_KIND,
-    _POS_KIND,
     TIMESTEP_FREQ_DIM,
     DeviceSession,
     _ArchRegistry,
     _check_supported,
+    extra_layer_spec,
+    final_norm_absent,
     normalizer_config_for,
     normalizer_spec,
+    tower_desc,
 )
 from lcm.nn.incremental_state import LCMIncrementalStateBag
 from lcm.nn.transformer_config import ProjectionConfig, TransformerConfig
@@ -105,7 +106,9 @@ def parameter_spec(config: BaseLCModelConfig,
         spec.append((f"{p}.ffn.inner_proj.bias", (F,), "zeros"))
         spec.append((f"{p}.ffn.output_proj.weight", (d, F), "matrix"))
         spec.append((f"{p}.ffn.output_proj.bias", (d,), "zeros"))
-    norm("lcm.layer_norm")
+        extra_layer_spec(spec, p, tc, d, norm)
+    if not final_norm_absent(tc):
+        norm("lcm.layer_norm")
     spec.append(("postnet.fc.weight", (D, d), "matrix"))
     if config.postnet.linear_bias:
         spec.append(("postnet.fc.bias", (D,), "zeros"))
@@ -167,6 +170,8 @@ class BaseLCModel(AbstractLCModel):
                 t.zero_()
             elif kind == "ones":
                 t.fill_(1.0)
+            elif kind.startswith("const:"):
+                t.fill_(float(kind[6:]))
             else:
                 std = matrix_std if kind == "matrix" else self.config.frontend.embedding_std
                 t.copy_(torch.randn(shape, generator=g, device=t.device, dtype=torch.float32) * std)
@@ -192,13 +197,7 @@ class BaseLCModel(AbstractLCModel):
 
     def _bind(self) -> None:
         c, tc = self.config, self.config.lcm
-        tower = _hip.TowerDesc(
-            num_layers=tc.num_layers, num_heads=tc.num_attn_heads, ffn_dim=tc.allocated_ffn_dim(),
-            norm_kind=_NORM_KIND[tc.layer_normalization_style],
-            ffn_kind=_hip.FFN_SWIGLU if tc.use_swiglu else _hip.FFN_RELU,
-            pos_kind=_POS_KIND[tc.pos_embedding_style], out_proj_bias=int(tc.mha_output_proj_bias),
-            rope_theta=float(tc.rope_theta), qk_layernorm=int(tc.enable_qk_layernorm),
-                ffn_activation=_hip.ACT.get(tc.ffn_inner_activation_name, 0))
+        tower = tower_desc(tc)
         none = _hip.TowerDesc(num_layers=0)      # no denoiser tower: selects the base LCM in the library
         desc = _hip.ModelDesc(sonar_dim=c.sonar_embed_dim, model_dim=c.model_dim, max_seq_len=c.max_seq_len,
                               timestep_freq_dim=TIMESTEP_FREQ_DIM, dtype=_hip.dtype_code(self.dtype), norm_eps=1e-5,

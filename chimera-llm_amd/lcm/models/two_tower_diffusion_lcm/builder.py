@@ -59,25 +59,68 @@ lcm_archs = _ArchRegistry()
 lcm_arch = lcm_archs.decorator
 
 _NORM_KIND = {"standard": _hip.NORM_LAYERNORM, "rms": _hip.NORM_RMS, "fp32": _hip.NORM_FP32, "unit": _hip.NORM_UNIT}
-_POS_KIND = {"none": _hip.POS_NONE, "learned": _hip.POS_LEARNED, "rope": _hip.POS_ROPE}
+_POS_KIND = {"none": _hip.POS_NONE, "learned": _hip.POS_LEARNED, "rope": _hip.POS_ROPE, "sine": _hip.POS_SINE}
 TIMESTEP_FREQ_DIM = 256
 
 
-def _check_supported(name: str, tc: TransformerConfig) -> None:
+def _check_supported(name: str, tc: TransformerConfig, denoiser: bool = False) -> None:
+    """Options of a stack the HIP path does not implement raise here, at construction.  The denoiser's layers are
+    pre-norm in the reference too (lcm/nn/denoisers/lcm_denoiser.py:441-443 asserts against "post"); its factory never
+    forwards `scale_residual` (lcm/nn/denoisers/factory.py:181-191) and its stack's final norm follows norm_order_style
+    alone (:132-151), so those two settings are accepted for the denoiser and have no effect, as in the reference."""
     bad = []
     if tc.layer_normalization_style not in _NORM_KIND:
         bad.append(f"layer_normalization_style={tc.layer_normalization_style}")
-    if tc.norm_order_style != "pre" or tc.final_norm_order_style not in (None, "pre"):
-        bad.append("only pre-norm stacks")
-    if tc.pos_embedding_style not in _POS_KIND:
-        bad.append(f"pos_embedding_style={tc.pos_embedding_style}")
-    if tc.scale_residual is not None:
-        bad.append("scale_residual")
+    if denoiser:
+        if tc.norm_order_style != "pre":
+            bad.append(f"norm_order_style={tc.norm_order_style} (denoiser layers are pre-norm)")
+        if tc.pos_embedding_style not in ("none", "learned"):
+            bad.append(f"pos_embedding_style={tc.pos_embedding_style} on the denoiser")
+    else:
+        if tc.norm_order_style not in _hip.ORDER or tc.final_norm_order_style not in (None,) + tuple(_hip.ORDER):
+            bad.append(f"norm order {tc.norm_order_style} / {tc.final_norm_order_style}")
+        if tc.pos_embedding_style not in _POS_KIND:
+            bad.append(f"pos_embedding_style={tc.pos_embedding_style}")
     if not tc.use_swiglu and tc.ffn_inner_activation_name not in _hip.ACT:
         # "prelu" carries a learned slope (a parameter of the activation module); anything else is unknown to the reference too
         bad.append(f"ffn activation {tc.ffn_inner_activation_name}")
     if bad:
         raise NotImplementedError(f"{name}: not implemented on the HIP path: {', '.join(bad)}")
+
+
+def final_norm_absent(tc: TransformerConfig) -> bool:
+    """A contextualizer / base-LCM stack ends without a LayerNorm when its final order is "post"
+    (lcm/models/two_tower_diffusion_lcm/builder.py:583-595, lcm/nn/transformer/decoder.py:119-122)."""
+    return (tc.final_norm_order_style or tc.norm_order_style) == "post"
+
+
+def extra_layer_spec(spec: list, p: str, tc: TransformerConfig, d: int, norm: Callable[[str], None]) -> None:
+    """Per-layer tensors of the non-default layer options of a contextualizer / base-LCM stack: the normformer order's
+    norm after the attention block (the stack's norm style) and fairseq2's LayerNorm (weight + bias) on the two-matrix
+    FFN's inner activations; the learned residual scale of the FFN block, initialised at `scale_residual`
+    (lcm/nn/transformer/factory.py:172-184)."""
+    if tc.norm_order_style == "normformer":
+        norm(f"{p}.self_attn_norm")
+        if not tc.use_swiglu:
+            F = tc.allocated_ffn_dim()
+            spec.append((f"{p}.ffn.inner_layer_norm.weight", (F,), "ones"))
+            spec.append((f"{p}.ffn.inner_layer_norm.bias", (F,), "zeros"))
+    if tc.scale_residual is not None:
+        spec.append((f"{p}.residual_scale", (d,), f"const:{float(tc.scale_residual)}"))
+
+
+def tower_desc(tc: TransformerConfig, denoiser: bool = False) -> "_hip.TowerDesc":
+    """lcmhip_tower_desc of one stack."""
+    return _hip.TowerDesc(
+        num_layers=tc.num_layers, num_heads=tc.num_attn_heads, ffn_dim=tc.allocated_ffn_dim(),
+        norm_kind=_NORM_KIND[tc.layer_normalization_style],
+        ffn_kind=_hip.FFN_SWIGLU if tc.use_swiglu else _hip.FFN_RELU,
+        pos_kind=_POS_KIND[tc.pos_embedding_style], out_proj_bias=int(tc.mha_output_proj_bias),
+        rope_theta=float(tc.rope_theta), qk_layernorm=int(tc.enable_qk_layernorm),
+        ffn_activation=_hip.ACT.get(tc.ffn_inner_activation_name, 0),
+        norm_order=0 if denoiser else _hip.ORDER[tc.norm_order_style],
+        no_final_norm=0 if denoiser else int(final_norm_absent(tc)),
+        scale_residual=0 if denoiser else int(tc.scale_residual is not None))
 
 
 def normalizer_config_for(name: Optional[str], dim: int) -> SonarNormalizerConfig:
@@ -154,7 +197,10 @@ def parameter_spec(config: TwoTowerDiffusionLCModelConfig,
             if denoiser:
                 spec.append((f"{p}.modulator.fc.weight", (9 * d, d), "modulator"))
                 spec.append((f"{p}.modulator.fc.bias", (9 * d,), "modulator"))
-        norm(f"{prefix}.layer_norm")
+            else:
+                extra_layer_spec(spec, p, tc, d, norm)
+        if denoiser or not final_norm_absent(tc):
+            norm(f"{prefix}.layer_norm")
 
     stack("context_encoder", config.context_encoder, denoiser=False)
     spec += [
@@ -358,7 +404,7 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
         dtype = dtype or torch.float32
         _hip.dtype_code(dtype)
         _check_supported("context_encoder", config.context_encoder)
-        _check_supported("denoiser", config.denoiser)
+        _check_supported("denoiser", config.denoiser, denoiser=True)
         if config.denoiser.timestep_embed_dim != config.model_dim:
             raise ValueError("timestep_embed_dim must equal model_dim")
         self.model_dim = config.model_dim
@@ -403,6 +449,8 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
                 t.zero_()
             elif kind == "ones":
                 t.fill_(1.0)
+            elif kind.startswith("const:"):
+                t.fill_(float(kind[6:]))
             else:
                 std = {"matrix": matrix_std, "pos": self.config.frontend.embedding_std, "modulator": modulator_std}[kind]
                 if std == 0.0:
@@ -470,18 +518,9 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
     def _bind(self) -> None:
         c = self.config
 
-        def tower(tc: TransformerConfig) -> _hip.TowerDesc:
-            return _hip.TowerDesc(
-                num_layers=tc.num_layers, num_heads=tc.num_attn_heads, ffn_dim=tc.allocated_ffn_dim(),
-                norm_kind=_NORM_KIND[tc.layer_normalization_style],
-                ffn_kind=_hip.FFN_SWIGLU if tc.use_swiglu else _hip.FFN_RELU,
-                pos_kind=_POS_KIND[tc.pos_embedding_style], out_proj_bias=int(tc.mha_output_proj_bias),
-                rope_theta=float(tc.rope_theta), qk_layernorm=int(tc.enable_qk_layernorm),
-                ffn_activation=_hip.ACT.get(tc.ffn_inner_activation_name, 0))
-
         desc = _hip.ModelDesc(sonar_dim=c.sonar_embed_dim, model_dim=c.model_dim, max_seq_len=c.max_seq_len,
                               timestep_freq_dim=TIMESTEP_FREQ_DIM, dtype=_hip.dtype_code(self.dtype), norm_eps=1e-5,
-                              context=tower(c.context_encoder), denoiser=tower(c.denoiser))
+                              context=tower_desc(c.context_encoder), denoiser=tower_desc(c.denoiser, denoiser=True))
         _hip.check(_hip.lib.lcmhip_model_create(C.byref(desc), C.byref(self._handle)))
         code = _hip.dtype_code(self.dtype)
         for name, t in list(self._params.items()) + list(self._derived.items()):

@@ -28,10 +28,11 @@ extern "C" {
 #endif
 
 /* Version of this ABI (struct layouts and signatures).  lcmhip_version() returns the value the library was built
- * with; a caller built against another value must not bind.  200 -> 300: lcmhip_session_workspace_bytes and
+ * with; a caller built against another value must not bind.  300 -> 400: lcmhip_tower_desc.norm_order,
+ * no_final_norm and scale_residual, LCMHIP_POS_SINE; 200 -> 300: lcmhip_session_workspace_bytes and
  * lcmhip_session_create take `flags`, lcmhip_static_init added, lcmhip_tower_desc.ffn_activation; 100 -> 200: lcmhip_tower_desc.qk_layernorm,
  * thresholding fields of lcmhip_denoise_params, variance_noise of lcmhip_ddim_cfg_step. */
-#define LCMHIP_ABI_VERSION 300
+#define LCMHIP_ABI_VERSION 400
 
 #define LCMHIP_OK 0
 #define LCMHIP_ERR_INVALID (-1)     /* bad argument / shape the kernels do not support */
@@ -51,7 +52,17 @@ enum {
     LCMHIP_ACT_RELU = 0, LCMHIP_ACT_TANH = 1, LCMHIP_ACT_ELU = 2, LCMHIP_ACT_LEAKY_RELU = 3, LCMHIP_ACT_SELU = 4,
     LCMHIP_ACT_GELU = 5, LCMHIP_ACT_SILU = 6, LCMHIP_ACT_SOFTSIGN = 7, LCMHIP_ACT_SIGMOID = 8, LCMHIP_ACT_HARDSIGMOID = 9
 };
-enum { LCMHIP_POS_NONE = 0, LCMHIP_POS_LEARNED = 1, LCMHIP_POS_ROPE = 2 };
+/* lcm/nn/transformer/factory.py:79-87.  SINE: fairseq2's SinusoidalPositionEncoder, added by the frontend in fp32 --
+ * row p = [sin(p f_0) .. sin(p f_{h-1}), cos(p f_0) .. cos(p f_{h-1})], h = model_dim / 2, f_i = exp(-i ln(10000) / (h - 1));
+ * the contextualizer / base-LCM stack only. */
+enum { LCMHIP_POS_NONE = 0, LCMHIP_POS_LEARNED = 1, LCMHIP_POS_ROPE = 2, LCMHIP_POS_SINE = 3 };
+/* lcm/nn/transformer/factory.py:95-98, lcm/nn/transformer/decoder.py:55-88 (the contextualizer / base-LCM stack; the
+ * denoiser's layers are pre-norm, lcm/nn/denoisers/lcm_denoiser.py:441-443).
+ *  PRE:        x += attn(norm(x));             x += ffn(norm(x))
+ *  POST:       x  = norm(x + attn(x));         x  = norm(x + ffn(x))
+ *  NORMFORMER: x += attn_norm(attn(norm(x)));  x += ffn'(norm(x)), ffn' with a LayerNorm (weight + bias) on the inner
+ *              activations of the two-matrix FFN; tensors <layer>.self_attn_norm.* and <layer>.ffn.inner_layer_norm.* */
+enum { LCMHIP_ORDER_PRE = 0, LCMHIP_ORDER_POST = 1, LCMHIP_ORDER_NORMFORMER = 2 };
 enum { LCMHIP_PRED_SAMPLE = 0, LCMHIP_PRED_EPSILON = 1, LCMHIP_PRED_V = 2 };
 
 /* GEMM epilogues of lcmhip_gemm (C = A * W^T, W stored (N, K) like torch.nn.Linear.weight) */
@@ -81,6 +92,11 @@ typedef struct {
                               projections, before the head split and RoPE; lcm/nn/transformer/attention.py:143-199.
                               Tensors <attn>.q_layer_norm.* and <attn>.k_layer_norm.* */
     int32_t ffn_activation; /* LCMHIP_ACT_*: inner activation when ffn_kind == LCMHIP_FFN_RELU (0 = ReLU) */
+    int32_t norm_order;     /* LCMHIP_ORDER_* of the layers (context stack; the denoiser takes PRE only) */
+    int32_t no_final_norm;  /* 1: the stack does not end with a LayerNorm -- final_norm_order_style (or, when that is
+                               None, norm_order_style) is "post"; lcm/models/two_tower_diffusion_lcm/builder.py:583-595 */
+    int32_t scale_residual; /* 1: the FFN block's residual is multiplied by the learned vector <layer>.residual_scale
+                               (model_dim) before the branch is added (factory.py:120-121, 172-184); context stack */
 } lcmhip_tower_desc;
 
 /* lcm/models/two_tower_diffusion_lcm/builder.py:49-81 (TwoTowerDiffusionLCModelConfig). */

@@ -23,10 +23,14 @@ class TowerConfig:
     use_swiglu: bool = False
     activation: str = "relu"
     norm: str = "standard"             # "standard" (LayerNorm w+b) | "rms"
-    pos: str = "learned"               # "learned" | "rope" | "none"
+    pos: str = "learned"               # "learned" | "rope" | "sine" | "none"
     rope_theta: float = 10000.0
     out_proj_bias: bool = False
     qk_layernorm: bool = False         # LayerNorm on q and k after their projections (attention.py:143-199)
+    # contextualizer / base-LCM stacks only (lcm/nn/transformer/factory.py:95-102, 120-121)
+    norm_order: str = "pre"            # "pre" | "post" | "normformer"
+    final_norm_order: str = None       # None: the layers' order; "post": the stack ends without its LayerNorm
+    scale_residual: bool = False       # the FFN block's residual is multiplied by <layer>.residual_scale
 
     def ffn_dim(self) -> int:
         return glu_inner_dim(self.ffn_inner_dim) if self.use_swiglu else self.ffn_inner_dim

@@ -102,6 +102,17 @@ def sdpa(q: Tensor, k: Tensor, v: Tensor, key_lens: Optional[Tensor], mask: Opti
     return torch.matmul(p, v.float()).type_as(q)
 
 
+def sinusoidal_positions(start: int, n: int, dim: int) -> Tensor:
+    """fairseq2 SinusoidalPositionEncoder as lcm/nn/transformer/factory.py:199-204 builds it (no legacy padding
+    offset): an fp32 table, row p = [sin(p f_0) .. sin(p f_{h-1}), cos(p f_0) .. cos(p f_{h-1})] with h = dim / 2 and
+    f_i = exp(-i ln(10000) / (h - 1)); the encoder adds it to the sequence in fp32 and casts back."""
+    h = dim // 2
+    steps = torch.arange(start, start + n, dtype=torch.float32)
+    freqs = torch.exp(torch.arange(h, dtype=torch.float32) * (-math.log(10000.0) / (h - 1)))
+    ang = torch.outer(steps, freqs)
+    return torch.cat([ang.sin(), ang.cos()], dim=-1)
+
+
 def causal_mask(attn_len: int, key_len: int) -> Optional[Tensor]:
     """fairseq2 CausalAttentionMaskFactory in eval: None when a single position is fed
     (incremental decode attends to every cached key); otherwise the last `attn_len` rows of a
@@ -205,7 +216,12 @@ class OracleTwoTower:
         if tc.use_swiglu:   # fairseq2 GLUFeedForwardNetwork: output(inner(x) * silu(gate(x)))
             return linear(linear(x, sd, prefix + ".inner_proj") * F.silu(linear(x, sd, prefix + ".gate_proj")),
                           sd, prefix + ".output_proj")
-        return linear(ACTIVATIONS[tc.activation](linear(x, sd, prefix + ".inner_proj")), sd, prefix + ".output_proj")
+        h = ACTIVATIONS[tc.activation](linear(x, sd, prefix + ".inner_proj"))
+        if prefix + ".inner_layer_norm.weight" in sd:
+            # fairseq2 StandardFeedForwardNetwork built with the normformer order (factory.py:292-300): its default
+            # LayerNorm (weight + bias) on the inner activations, before the output projection
+            h = norm(h, sd, prefix + ".inner_layer_norm", "standard", self.cfg.norm_eps)
+        return linear(h, sd, prefix + ".output_proj")
 
     # -- contextualizer (builder.py:161-191)
     def encode(self, x_norm: Tensor, cache: Optional[KVCache] = None, *, frontend: str = "encoder_frontend",
@@ -217,15 +233,33 @@ class OracleTwoTower:
         x = linear(x_norm, sd, frontend + ".pre_linear")                     # frontend.py:139
         if tc.pos == "learned":                                             # frontend.py:141-147
             x = x + sd[frontend + ".pos_encoder.weight"][start:start + S]
+        elif tc.pos == "sine":
+            x = (x.float() + sinusoidal_positions(start, S, x.shape[-1])).to(x.dtype)
         mask = causal_mask(S, start + S)                                     # decoder.py:145-152
+        order = getattr(tc, "norm_order", "pre")
+        final_order = getattr(tc, "final_norm_order", None) or order
         for i in range(tc.num_layers):
             p = f"{decoder}.layers.{i}"
-            h = norm(x, sd, p + ".self_attn_layer_norm", tc.norm, cfg.norm_eps)
-            x = x + self._mha(p + ".self_attn", tc, h, h, mask=mask, cache=cache, layer=i,
-                              use_rope=(tc.pos == "rope"))                   # decoder.py:55-88
-            h = norm(x, sd, p + ".ffn_layer_norm", tc.norm, cfg.norm_eps)
-            x = x + self._ffn(p + ".ffn", tc, h)
-        return norm(x, sd, decoder + ".layer_norm", tc.norm, cfg.norm_eps)        # decoder.py:170-171
+            # attention block: decoder.py:55-88 (no residual scale here)
+            h = x if order == "post" else norm(x, sd, p + ".self_attn_layer_norm", tc.norm, cfg.norm_eps)
+            a = self._mha(p + ".self_attn", tc, h, h, mask=mask, cache=cache, layer=i, use_rope=(tc.pos == "rope"))
+            if order == "normformer":
+                a = norm(a, sd, p + ".self_attn_norm", tc.norm, cfg.norm_eps)
+            x = a + x
+            if order == "post":
+                x = norm(x, sd, p + ".self_attn_layer_norm", tc.norm, cfg.norm_eps)
+            # FFN block: fairseq2 StandardTransformerDecoderLayer._forward_ffn, which LCMStandardTransformerDecoderLayer
+            # inherits -- the one place the learned residual scale is applied
+            h = x if order == "post" else norm(x, sd, p + ".ffn_layer_norm", tc.norm, cfg.norm_eps)
+            f = self._ffn(p + ".ffn", tc, h)
+            if getattr(tc, "scale_residual", False):
+                x = sd[p + ".residual_scale"] * x
+            x = f + x
+            if order == "post":
+                x = norm(x, sd, p + ".ffn_layer_norm", tc.norm, cfg.norm_eps)
+        if final_order == "post":                                            # decoder.py:119-122, 170-171
+            return x
+        return norm(x, sd, decoder + ".layer_norm", tc.norm, cfg.norm_eps)
 
     # -- timestep embedding (lcm/nn/timestep_encoder.py:72-122)
     def embed_time(self, timesteps: Tensor) -> Tensor:

@@ -78,6 +78,22 @@ def _tower_shapes(prefix: str, d: int, tc: TowerConfig, cross: bool, modulator: 
         if modulator:
             yield f"{p}.modulator.fc.weight", (9 * d, d), "mod_w"
             yield f"{p}.modulator.fc.bias", (9 * d,), "mod_b"
+        elif not cross:
+            # contextualizer / base-LCM stacks: the normformer order's extra norms and the learned residual scale
+            # (lcm/nn/transformer/factory.py:165-184, 292-300)
+            if getattr(tc, "norm_order", "pre") == "normformer":
+                if tc.norm != "unit":
+                    yield f"{p}.self_attn_norm.weight", (d,), "norm_w"
+                if tc.norm == "standard":
+                    yield f"{p}.self_attn_norm.bias", (d,), "norm_b"
+                if not tc.use_swiglu:
+                    yield f"{p}.ffn.inner_layer_norm.weight", (F,), "norm_w"
+                    yield f"{p}.ffn.inner_layer_norm.bias", (F,), "norm_b"
+            if getattr(tc, "scale_residual", False):
+                yield f"{p}.residual_scale", (d,), "res_scale"
+    final_post = (getattr(tc, "final_norm_order", None) or getattr(tc, "norm_order", "pre")) == "post"
+    if not cross and final_post:
+        return
     if tc.norm != "unit":
         yield f"{prefix}.layer_norm.weight", (d,), "norm_w"
     if tc.norm == "standard":
@@ -173,6 +189,8 @@ def init_state_dict(cfg: ArchConfig, seed: int = 0, *, w_std: float = 0.02, b_st
             sd[name] = 1.0 + _normal(seed, name, shape, norm_jitter)
         elif kind == "norm_b":
             sd[name] = _normal(seed, name, shape, norm_jitter)
+        elif kind == "res_scale":             # around 0.5, away from the neutral 1
+            sd[name] = 0.5 + _normal(seed, name, shape, 0.1)
         else:
             raise AssertionError(kind)
     return sd

@@ -81,7 +81,7 @@ def test_model_table_validation_without_gpu(hip):
     assert hip.lib.lcmhip_model_create(C.byref(desc), C.byref(handle)) == -3
 
 
-def test_library_override_and_version_gate(tmp_path):
+def test_library_override_and_version_gate(tmp_path, hip):
     """LCMHIP_LIB loads another build of the same ABI; a path that does not exist is an ImportError, never a silent
     fallback to the default library (or to anything on the CPU)."""
     import subprocess
@@ -93,7 +93,7 @@ def test_library_override_and_version_gate(tmp_path):
     env = dict(os.environ, LCMHIP_LIB=str(copy), PYTHONPATH=root)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
-    assert out.stdout.split()[0] == str(copy) and int(out.stdout.split()[1]) == 300
+    assert out.stdout.split()[0] == str(copy) and int(out.stdout.split()[1]) == hip.ABI_VERSION
     env["LCMHIP_LIB"] = str(tmp_path / "missing.so")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and "ImportError" in out.stderr

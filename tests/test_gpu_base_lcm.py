@@ -223,3 +223,40 @@ def test_base_teacher_forced_scorer(arch, sample):
             for ha, hb in zip(runs["one pass"], runs[name]):
                 a, b = ha[0].seq.float(), hb[0].seq.float()
                 assert (a - b).abs().max() <= 1e-3 * max(1.0, float(b.abs().max())), name
+
+
+@pytest.mark.parametrize("order,final,pos", [("post", None, "sine"), ("normformer", "post", "rope")])
+def test_base_layer_orders_forward_and_generation(order, final, pos):
+    """Post-norm / normformer layers, a stack without its final norm, the learned residual scale and sinusoidal
+    positions on the base LCM's decoder (lcm/nn/transformer/factory.py:79-121): whole-sequence forward over 450 rows (the
+    many-row kernels) and cached generation against the oracle, fp32; bf16 forward to the bf16 bar."""
+    from lcm.datasets.batch import EmbeddingsBatch
+    from lcm.models.base_lcm import create_base_lcm_model
+    from oracle.weights import synthetic_noise, synthetic_prompts
+    arch = "mini_base_lcm"
+    cfg = oracle.get_base_arch(arch)
+    cfg.lcm.norm_order, cfg.lcm.final_norm_order, cfg.lcm.pos, cfg.lcm.scale_residual = order, final, pos, True
+    sd = oracle.init_state_dict(cfg, seed=5, qk_gain=2.0, norm_jitter=0.2)
+    assert "lcm.layer_norm.weight" not in sd and "lcm.layers.2.residual_scale" in sd
+    mc = base_config(arch)
+    mc.lcm.norm_order_style, mc.lcm.final_norm_order_style, mc.lcm.pos_embedding_style, mc.lcm.scale_residual = order, final, pos, 0.5
+    model = create_base_lcm_model(mc, device="cuda:0", dtype=torch.float32)
+    assert set(model.state_dict()) == set(sd)
+    model.load_state_dict(sd)
+    x = synthetic_prompts(oracle.load_dummy_normalizer(), 5, 90, seed=87)
+    ref = oracle.OracleBaseLCM(cfg, sd).predict(x)
+    out = model.predict_next_sentence(EmbeddingsBatch(x.cuda(), None)).seqs.cpu()
+    assert (out - ref).abs().max() <= 2e-4 * ref.abs().max()
+    assert torch.nn.functional.cosine_similarity(out, ref, dim=-1).min() >= FP32_COS
+    nz = synthetic_noise(8, 5, seed=88)
+    opts = dict(OPTS, lcm_temperature=0.5)
+    ref_g = run_oracle_base(cfg, sd, x[:, :4], nz, 4, opts)
+    out_g, _ = run_hip_base(arch, sd, x[:, :4], nz, 4, opts, model=model)
+    worst, cos = compare(out_g.hypotheses, ref_g, _norm_sd(sd), start=4)
+    assert worst <= FP32_MAX_ABS and cos >= FP32_COS, (worst, cos)
+    sd16 = {k: v.bfloat16().float() for k, v in sd.items()}
+    ref16 = oracle.OracleBaseLCM(cfg, sd16).predict(x.bfloat16().float())
+    m16 = create_base_lcm_model(mc, device="cuda:0", dtype=torch.bfloat16)
+    m16.load_state_dict(sd)
+    out16 = m16.predict_next_sentence(EmbeddingsBatch(x.cuda().bfloat16(), None)).seqs.float().cpu()
+    assert torch.nn.functional.cosine_similarity(out16, ref16, dim=-1).min() >= BF16_COS

@@ -360,3 +360,79 @@ def test_weight_normalized_checkpoint():
     out, _ = run_hip(arch, sd, x, nz, 2, opts, model=model)
     worst, cos = compare(out.hypotheses, ref, sd, start=3)
     assert worst <= 1e-3 and cos >= 0.9999, (worst, cos)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("order,final,scale,pos,swiglu,norm", [
+    ("post", None, False, "rope", True, "rms"),               # post-norm layers, hence no final norm
+    ("post", "pre", True, "learned", False, "standard"),      # post-norm layers + the stack's norm; residual scale
+    ("pre", "post", True, "sine", True, "rms"),               # pre-norm layers without the final norm; sine positions
+    ("normformer", None, False, "rope", False, "standard"),   # two-matrix FFN: LayerNorm on its inner activations
+    ("normformer", None, True, "sine", True, "unit"),
+])
+def test_contextualizer_layer_options(order, final, scale, pos, swiglu, norm, dtype):
+    """norm_order_style / final_norm_order_style / scale_residual / pos_embedding_style="sine" of the contextualizer
+    (lcm/nn/transformer/factory.py:79-121, lcm/nn/transformer/decoder.py:55-88, 119-122; fairseq2's FFN block and
+    sinusoidal encoder restated in the oracle): ragged prompts, guidance on, against the oracle."""
+    cfg = O.get_arch(ARCH)
+    cx = cfg.context
+    cx.norm_order, cx.final_norm_order, cx.scale_residual, cx.pos, cx.use_swiglu, cx.norm = order, final, scale, pos, swiglu, norm
+    sd = O.init_state_dict(cfg, seed=8, mod_gain=4.0, qk_gain=1.5, norm_jitter=0.2, pos_std=0.5)
+    assert ("context_encoder.layer_norm.weight" in sd) == ((final or order) != "post" and norm != "unit")
+    assert ("context_encoder.layers.1.residual_scale" in sd) == scale
+    assert ("context_encoder.layers.0.ffn.inner_layer_norm.bias" in sd) == (order == "normformer" and not swiglu)
+    from oracle.weights import synthetic_noise, synthetic_prompts
+    nrm = {"center": sd["sonar_normalizer.center"], "scale": sd["sonar_normalizer.scale"]}
+    lens = [5, 2, 4]
+    x, nz = synthetic_prompts(nrm, 3, 5, seed=29), synthetic_noise(8, 3, seed=30)
+    opts = dict(DEFAULT_OPTS, inference_timesteps=10, guidance_scale=2.0)
+    if dtype == torch.bfloat16:
+        sd = {k: O.r16(v) for k, v in sd.items()}
+        x = O.r16(x)
+    ref = O.OracleGenerator(O.OracleTwoTower(cfg, sd), O.GenOptions(**opts))(x, prompt_lens=torch.tensor(lens), max_gen_len=3, noise=nz)
+    from lcm.models.two_tower_diffusion_lcm import create_two_tower_diffusion_lcm_model
+    mc = mini_config()
+    tc = mc.context_encoder
+    tc.norm_order_style, tc.final_norm_order_style, tc.pos_embedding_style = order, final, pos
+    tc.scale_residual = 0.5 if scale else None
+    tc.use_swiglu, tc.layer_normalization_style = swiglu, norm
+    model = create_two_tower_diffusion_lcm_model(mc, device="cuda:0", dtype=dtype)
+    assert set(model.state_dict()) == set(sd)
+    if scale:   # the learned scale starts at the configured constant (factory.py:177-184)
+        assert torch.all(model.state_dict()["context_encoder.layers.0.residual_scale"] == 0.5)
+    model.load_state_dict(sd)
+    out = _hip_generate(model, x, nz, 3, opts, prompt_lens=lens)
+    worst, cos = compare(out.hypotheses, ref, sd)
+    if dtype == torch.float32:
+        assert worst <= FP32_MAX_ABS and cos >= FP32_COS, (worst, cos)
+        # the options matter on this problem: the default stack with the same weights gives other sentences
+        cfg2 = O.get_arch(ARCH)
+        cfg2.context.use_swiglu, cfg2.context.norm = swiglu, norm
+        cfg2.context.pos = pos if pos != "sine" else "none"
+        sd2 = dict(sd)
+        for k in ("weight", "bias"):
+            sd2.setdefault(f"context_encoder.layer_norm.{k}", torch.ones(256) if k == "weight" else torch.zeros(256))
+        plain = O.OracleGenerator(O.OracleTwoTower(cfg2, sd2), O.GenOptions(**opts))(x, prompt_lens=torch.tensor(lens), max_gen_len=3, noise=nz)
+        w_plain, _ = compare(out.hypotheses, plain, sd)
+        assert w_plain > 10 * FP32_MAX_ABS, w_plain
+    else:
+        assert cos >= BF16_COS, (worst, cos)
+
+
+def test_denoiser_options_the_reference_ignores_or_refuses():
+    """The denoiser's layers are pre-norm (lcm_denoiser.py:441-443 asserts it), so other orders are refused at
+    construction; `scale_residual` and `final_norm_order_style` never reach them (denoisers/factory.py:132-191) and are
+    accepted without effect: the state dict has no residual scale and keeps the final norm."""
+    from lcm.models.two_tower_diffusion_lcm import create_two_tower_diffusion_lcm_model
+    mc = mini_config()
+    mc.denoiser.norm_order_style = "post"
+    with pytest.raises(NotImplementedError):
+        create_two_tower_diffusion_lcm_model(mc, device="cuda:0", dtype=torch.float32)
+    mc = mini_config()
+    mc.denoiser.pos_embedding_style = "sine"
+    with pytest.raises(NotImplementedError):
+        create_two_tower_diffusion_lcm_model(mc, device="cuda:0", dtype=torch.float32)
+    mc = mini_config()
+    mc.denoiser.scale_residual, mc.denoiser.final_norm_order_style = 0.5, "post"
+    model = create_two_tower_diffusion_lcm_model(mc, device="cuda:0", dtype=torch.float32)
+    assert set(model.state_dict()) == set(create_two_tower_diffusion_lcm_model(mini_config(), device="cuda:0", dtype=torch.float32).state_dict())

@@ -9,6 +9,7 @@ test_base_lcm_batched_inference.py:21-155, tests/units/models/test_lcm_architect
 and analytic identities of the algorithm.
 """
 
+import math
 import os
 
 import pytest
@@ -17,7 +18,7 @@ import torch.nn.functional as F
 
 import oracle
 from oracle.archs import SchedulerConfig
-from oracle.model import KVCache, causal_mask, rope, rope_explicit, sdpa
+from oracle.model import KVCache, causal_mask, rope, rope_explicit, sdpa, sinusoidal_positions
 from oracle.weights import num_parameters, synthetic_noise, synthetic_prompts
 
 OPTS = dict(guidance_scale=3.0, guidance_rescale=0.7, initial_noise_scale=0.6, eos_threshold=None)
@@ -368,3 +369,31 @@ def test_base_scorer_equals_one_causal_forward():
             got = hyps[i][0].seq
             assert got.shape == (n - mcl, 1024)
             assert torch.allclose(got, full[i, mcl - 1:n - 1], atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("order,final,pos,swiglu", [("post", None, "sine", True), ("normformer", None, "rope", False),
+                                                   ("pre", "post", "sine", True), ("post", "pre", "learned", False)])
+def test_contextualizer_options_cached_equals_full(order, final, pos, swiglu):
+    """The reference's KV-caching invariant (tests/units/inference/test_base_lcm_kv_caching.py:17-74) on the oracle's
+    statements of the non-default layer options: encoding position by position through the cache equals one causal
+    pass, so the order of norms / residual scale / sinusoidal offset is applied per position and not per call."""
+    cfg = oracle.get_arch("mini_two_tower_diffusion_lcm")
+    cx = cfg.context
+    cx.norm_order, cx.final_norm_order, cx.pos, cx.use_swiglu, cx.scale_residual = order, final, pos, swiglu, True
+    cx.norm = "standard" if not swiglu else "rms"
+    sd = oracle.init_state_dict(cfg, seed=2, qk_gain=1.5, norm_jitter=0.2)
+    model = oracle.OracleTwoTower(cfg, sd)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 7, 1024, generator=g)
+    full = model.encode(x)
+    cache = KVCache(16)
+    steps = []
+    for j in range(7):
+        steps.append(model.encode(x[:, j:j + 1], cache))
+        cache.increment_step_nr(1)
+    assert torch.allclose(torch.cat(steps, dim=1), full, atol=2e-5, rtol=1e-4)
+    # and the sinusoidal table is the closed form
+    tab = sinusoidal_positions(3, 2, 8)
+    f = torch.exp(torch.arange(4, dtype=torch.float64) * (-math.log(10000.0) / 3))
+    want = torch.cat([torch.sin(torch.tensor([[3.0], [4.0]], dtype=torch.float64) * f), torch.cos(torch.tensor([[3.0], [4.0]], dtype=torch.float64) * f)], -1)
+    assert torch.allclose(tab.double(), want, atol=1e-6)
