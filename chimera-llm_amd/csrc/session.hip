@@ -413,12 +413,13 @@ struct BaseOut {
     int all = 0;
 };
 
-// out[dst] = denormalize(y[r] + temperature * noise[dst]) for the rows of one append chunk
+// out[dst] = denormalize(act(y[r]) + temperature * noise[dst]) for the rows of one append chunk
 template <typename T>
 __global__ __launch_bounds__(128) void k_base_out(const float* __restrict__ y, const float* __restrict__ noise,
                                                   const T* __restrict__ center, const T* __restrict__ scale,
                                                   float* __restrict__ out, int D, int sc, int n_tokens, int j0, int all,
-                                                  float temperature, const T* __restrict__ cmin, const T* __restrict__ cmax) {
+                                                  float temperature, const T* __restrict__ cmin, const T* __restrict__ cmax,
+                                                  int act) {
     const int r = blockIdx.x;
     const int i = r / sc, j = j0 + r % sc;
     if (!all && j != n_tokens - 1) return;
@@ -426,6 +427,10 @@ __global__ __launch_bounds__(128) void k_base_out(const float* __restrict__ y, c
     for (int c = threadIdx.x * 8; c < D; c += blockDim.x * 8) {
         float v[8];
         load8<float>(y + (size_t)r * D + c, v);
+        if (act > 0) {   // the postnet's own activation (projection.py:83-84), before noise and denormalization
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = apply_act(v[t], act - 1);
+        }
         if (noise != nullptr) {
             float z[8];
             load8<float>(noise + dst * D + c, z);
@@ -631,6 +636,8 @@ int lcmhip_model_create(const lcmhip_model_desc* desc, lcmhip_model** out) {
             return fail(LCMHIP_ERR_UNSUPPORTED, "denoiser: pre-norm layers with a final norm and no residual scale only");
     }
     LCM_REQUIRE(desc->embed_scale >= 0.f, "model_create: embed_scale");
+    LCM_REQUIRE(desc->postnet_activation >= 0 && desc->postnet_activation <= 1 + LCMHIP_ACT_HARDSIGMOID && (base || desc->postnet_activation == 0),
+                "model_create: postnet_activation is 0 or 1 + LCMHIP_ACT_* (base LCM only)");
     {
         // the library's set-up call: resolves the static scratch of lcmhip_gemm_static on the current device (a model
         // table can also be built and validated on a host without a GPU: nothing to resolve there)
@@ -1120,11 +1127,11 @@ static int append_impl(lcmhip_session* s, const float* x, int32_t n_tokens, int3
                 if (d.dtype == LCMHIP_BF16)
                     hipLaunchKernelGGL((k_base_out<bf16_t>), dim3(R), dim3(128), 0, st, s->f32tmp, g_noise, (const bf16_t*)m->center,
                                        (const bf16_t*)m->scale, g_out, D, sc, n_tokens, j0, bo->all, bo->temperature,
-                                       (const bf16_t*)m->clip_min, (const bf16_t*)m->clip_max);
+                                       (const bf16_t*)m->clip_min, (const bf16_t*)m->clip_max, d.postnet_activation);
                 else
                     hipLaunchKernelGGL((k_base_out<float>), dim3(R), dim3(128), 0, st, s->f32tmp, g_noise, (const float*)m->center,
                                        (const float*)m->scale, g_out, D, sc, n_tokens, j0, bo->all, bo->temperature,
-                                       (const float*)m->clip_min, (const float*)m->clip_max);
+                                       (const float*)m->clip_min, (const float*)m->clip_max, d.postnet_activation);
                 LCM_HIP_CHECK(hipGetLastError());
             }
         }
@@ -1406,11 +1413,11 @@ int lcmhip_denoise_positions(lcmhip_session* s, const float* noisy, const int32_
             if (d.dtype == LCMHIP_BF16)
                 hipLaunchKernelGGL((k_base_out<bf16_t>), dim3(R), dim3(128), 0, st, s->f32tmp, (const float*)nullptr,
                                    (const bf16_t*)nullptr, (const bf16_t*)nullptr, g_out, D, sc, n_positions, j0, 1, 0.f,
-                                   (const bf16_t*)nullptr, (const bf16_t*)nullptr);
+                                   (const bf16_t*)nullptr, (const bf16_t*)nullptr, 0);
             else
                 hipLaunchKernelGGL((k_base_out<float>), dim3(R), dim3(128), 0, st, s->f32tmp, (const float*)nullptr,
                                    (const float*)nullptr, (const float*)nullptr, g_out, D, sc, n_positions, j0, 1, 0.f,
-                                   (const float*)nullptr, (const float*)nullptr);
+                                   (const float*)nullptr, (const float*)nullptr, 0);
             LCM_HIP_CHECK(hipGetLastError());
         }
     }

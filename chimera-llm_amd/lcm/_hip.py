@@ -54,7 +54,8 @@ class TowerDesc(C.Structure):
 class ModelDesc(C.Structure):
     _fields_ = [("sonar_dim", C.c_int32), ("model_dim", C.c_int32), ("max_seq_len", C.c_int32),
                 ("timestep_freq_dim", C.c_int32), ("dtype", C.c_int32), ("norm_eps", C.c_float),
-                ("context", TowerDesc), ("denoiser", TowerDesc), ("embed_scale", C.c_float)]
+                ("context", TowerDesc), ("denoiser", TowerDesc), ("embed_scale", C.c_float),
+                ("postnet_activation", C.c_int32)]
 
 
 class DenoiseParams(C.Structure):

@@ -136,8 +136,9 @@ class BaseLCModel(AbstractLCModel):
         _check_supported("lcm", config.lcm)
         if config.model_output_dim not in (None, config.sonar_embed_dim):
             raise NotImplementedError("model_output_dim other than the SONAR dimension is not implemented on the HIP path")
-        if config.postnet.activation_name is not None:
-            raise NotImplementedError("a postnet activation is not implemented on the HIP path")
+        if config.postnet.activation_name is not None and config.postnet.activation_name not in _hip.ACT:
+            # "prelu" carries a learned slope; anything else is unknown to the reference too (initialization.py:121-151)
+            raise NotImplementedError(f"postnet activation {config.postnet.activation_name} is not implemented on the HIP path")
         self.model_dim = config.model_dim
         self.sonar_embed_dim = config.sonar_embed_dim
         ncfg = normalizer_config_for(config.sonar_normalizer_name, config.sonar_embed_dim)
@@ -202,7 +203,8 @@ class BaseLCModel(AbstractLCModel):
         desc = _hip.ModelDesc(sonar_dim=c.sonar_embed_dim, model_dim=c.model_dim, max_seq_len=c.max_seq_len,
                               timestep_freq_dim=TIMESTEP_FREQ_DIM, dtype=_hip.dtype_code(self.dtype), norm_eps=1e-5,
                               context=tower, denoiser=none,
-                              embed_scale=float(c.model_dim ** 0.5) if c.frontend.scale_embeddings else 1.0)
+                              embed_scale=float(c.model_dim ** 0.5) if c.frontend.scale_embeddings else 1.0,
+                              postnet_activation=0 if c.postnet.activation_name is None else 1 + _hip.ACT[c.postnet.activation_name])
         _hip.check(_hip.lib.lcmhip_model_create(C.byref(desc), C.byref(self._handle)))
         code = _hip.dtype_code(self.dtype)
         for name, t in self._params.items():

@@ -155,8 +155,9 @@ def parameter_spec(config: TwoTowerDiffusionLCModelConfig,
     """(name, shape, kind) of every parameter/buffer, named like the reference's state dict."""
     d, D = config.model_dim, config.sonar_embed_dim
     spec: List[Tuple[str, Tuple[int, ...], str]] = normalizer_spec("sonar_normalizer", normalizer or SonarNormalizerConfig(dim=D)) + [
-        ("encoder_frontend.pre_linear.weight", (d, D), "matrix"), ("encoder_frontend.pre_linear.bias", (d,), "zeros"),
-    ]
+        ("encoder_frontend.pre_linear.weight", (d, D), "matrix")]
+    if config.frontend.pre_linear_bias:                 # frontend.py:24-36, 96-104
+        spec.append(("encoder_frontend.pre_linear.bias", (d,), "zeros"))
     if config.context_encoder.pos_embedding_style == "learned":
         spec.append(("encoder_frontend.pos_encoder.weight", (config.max_seq_len, d), "pos"))
 
@@ -206,9 +207,12 @@ def parameter_spec(config: TwoTowerDiffusionLCModelConfig,
     spec += [
         ("denoiser.embed_time.fc1.weight", (d, TIMESTEP_FREQ_DIM), "matrix"), ("denoiser.embed_time.fc1.bias", (d,), "zeros"),
         ("denoiser.embed_time.fc2.weight", (d, d), "matrix"), ("denoiser.embed_time.fc2.bias", (d,), "zeros"),
-        ("denoiser.initial_proj.fc.weight", (d, D), "matrix"), ("denoiser.initial_proj.fc.bias", (d,), "zeros"),
-        ("denoiser.final_proj.fc.weight", (D, d), "matrix"), ("denoiser.final_proj.fc.bias", (D,), "zeros"),
+        ("denoiser.initial_proj.fc.weight", (d, D), "matrix"), ("denoiser.final_proj.fc.weight", (D, d), "matrix"),
     ]
+    if config.denoiser.pre_denoiser.linear_bias:         # lcm/nn/projection.py:28, 60-67
+        spec.append(("denoiser.initial_proj.fc.bias", (d,), "zeros"))
+    if config.denoiser.post_denoiser.linear_bias:
+        spec.append(("denoiser.final_proj.fc.bias", (D,), "zeros"))
     if config.denoiser.pos_embedding_style == "learned":       # lcm/nn/transformer/factory.py:187-198
         spec.append(("denoiser.pos_encoder.weight", (config.max_seq_len, d), "pos"))
     stack("denoiser", config.denoiser, denoiser=True)
@@ -407,6 +411,10 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
         _check_supported("denoiser", config.denoiser, denoiser=True)
         if config.denoiser.timestep_embed_dim != config.model_dim:
             raise ValueError("timestep_embed_dim must equal model_dim")
+        for which in ("pre_denoiser", "post_denoiser"):
+            if getattr(config.denoiser, which).activation_name is not None:
+                # projection.py:73-86; the sampling loop folds these projections' split-K slabs into its neighbours
+                raise NotImplementedError(f"denoiser.{which}.activation_name is not implemented on the HIP path")
         self.model_dim = config.model_dim
         self.sonar_embed_dim = config.sonar_embed_dim
         ncfg = normalizer_config_for(config.sonar_normalizer_name, config.sonar_embed_dim)
@@ -421,6 +429,12 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
         for i in range(config.denoiser.num_layers):
             self._derived[f"denoiser.layers.{i}.self_attn.ov_proj.weight"] = torch.empty((d, d), dtype=dtype, device=device)
             self._derived[f"denoiser.layers.{i}.self_attn.ov_proj.bias"] = torch.empty((d,), dtype=dtype, device=device)
+        # a projection configured without a bias (frontend.pre_linear_bias, pre_denoiser / post_denoiser.linear_bias) has
+        # none in the state dict; the library takes a zero vector in its place
+        for name, n in (("encoder_frontend.pre_linear.bias", d), ("denoiser.initial_proj.fc.bias", d),
+                        ("denoiser.final_proj.fc.bias", config.sonar_embed_dim)):
+            if name not in self._params:
+                self._derived[name] = torch.zeros((n,), dtype=dtype, device=device)
         self._handle = None
         self.init_parameters(seed if seed is not None else 0)
         self.sonar_normalizer = SonarNormalizer(ncfg, device=device, dtype=dtype)

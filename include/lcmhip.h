@@ -29,7 +29,7 @@ extern "C" {
 
 /* Version of this ABI (struct layouts and signatures).  lcmhip_version() returns the value the library was built
  * with; a caller built against another value must not bind.  300 -> 400: lcmhip_tower_desc.norm_order,
- * no_final_norm and scale_residual, LCMHIP_POS_SINE; 200 -> 300: lcmhip_session_workspace_bytes and
+ * no_final_norm and scale_residual, LCMHIP_POS_SINE, lcmhip_model_desc.postnet_activation; 200 -> 300: lcmhip_session_workspace_bytes and
  * lcmhip_session_create take `flags`, lcmhip_static_init added, lcmhip_tower_desc.ffn_activation; 100 -> 200: lcmhip_tower_desc.qk_layernorm,
  * thresholding fields of lcmhip_denoise_params, variance_noise of lcmhip_ddim_cfg_step. */
 #define LCMHIP_ABI_VERSION 400
@@ -111,6 +111,8 @@ typedef struct {
     lcmhip_tower_desc denoiser;  /* num_layers == 0 selects the base LCM (lcm/models/base_lcm/builder.py:64-124):
                                     frontend -> causal decoder -> postnet, tensor names frontend.*, lcm.*, postnet.fc.* */
     float embed_scale;           /* frontend input scale, lcm/models/base_lcm/frontend.py:91, 170; 0 means 1 */
+    int32_t postnet_activation;  /* base LCM: activation after the output projection (ProjectionConfig.activation_name,
+                                    lcm/nn/projection.py:73-86); 0 = none, otherwise 1 + LCMHIP_ACT_* */
 } lcmhip_model_desc;
 
 /* Options of DiffusionLCMGeneratorOptions that reach the arithmetic

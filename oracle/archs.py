@@ -66,6 +66,9 @@ class ArchConfig:
     scheduler: SchedulerConfig = field(default_factory=SchedulerConfig)
     trained_with_cf_guidance: bool = False
     sonar_normalizer_name: str = "dummy_sonar_normalizer"
+    frontend_bias: bool = True             # two_tower_diffusion_lcm/frontend.py:24-36 pre_linear_bias
+    initial_proj_bias: bool = True         # lcm/nn/projection.py:28 on denoiser.pre_denoiser / post_denoiser
+    final_proj_bias: bool = True
 
 
 def _toy() -> ArchConfig:
@@ -107,6 +110,7 @@ class BaseArchConfig:
     lcm: TowerConfig = field(default_factory=TowerConfig)
     pre_linear_bias: bool = True           # base_lcm/frontend.py:30
     postnet_bias: bool = True              # lcm/nn/projection.py:28
+    postnet_activation: str = None         # lcm/nn/projection.py:37, 73-86
     scale_embeddings: bool = False         # base_lcm/frontend.py:35, 91
     sonar_normalizer_name: str = None      # abstract_lcm/builder.py:33: no normalizer unless named
 

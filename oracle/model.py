@@ -431,7 +431,9 @@ class OracleBaseLCM(OracleTwoTower):
         """builder.py:94-124 on already-normalized inputs; `embed_scale` per frontend.py:91, 170."""
         scale = self.cfg.model_dim ** 0.5 if self.cfg.scale_embeddings else 1.0
         h = self.encode(scale * x_norm, cache, frontend="frontend", decoder="lcm", tc=self.cfg.lcm)
-        return linear(h, self.sd, "postnet.fc")                              # projection.py:80-86
+        y = linear(h, self.sd, "postnet.fc")                                 # projection.py:80-86
+        act = getattr(self.cfg, "postnet_activation", None)
+        return y if act is None else ACTIVATIONS[act](y)
 
     def predict(self, x: Tensor, cache: Optional[KVCache] = None, noise: Optional[Tensor] = None,
                 sample: bool = False, temperature: float = 1.0) -> Tensor:

@@ -106,7 +106,8 @@ def state_dict_spec(cfg: ArchConfig):
     yield "sonar_normalizer.center", (D,), "normalizer"
     yield "sonar_normalizer.scale", (D,), "normalizer"
     yield "encoder_frontend.pre_linear.weight", (d, D), "w"
-    yield "encoder_frontend.pre_linear.bias", (d,), "b"
+    if getattr(cfg, "frontend_bias", True):
+        yield "encoder_frontend.pre_linear.bias", (d,), "b"
     if cfg.context.pos == "learned":
         yield "encoder_frontend.pos_encoder.weight", (cfg.max_seq_len, d), "pos"
     yield from _tower_shapes("context_encoder", d, cfg.context, cross=False, modulator=False)
@@ -115,9 +116,11 @@ def state_dict_spec(cfg: ArchConfig):
     yield "denoiser.embed_time.fc2.weight", (d, d), "t_w"
     yield "denoiser.embed_time.fc2.bias", (d,), "b"
     yield "denoiser.initial_proj.fc.weight", (d, D), "w"
-    yield "denoiser.initial_proj.fc.bias", (d,), "b"
+    if getattr(cfg, "initial_proj_bias", True):
+        yield "denoiser.initial_proj.fc.bias", (d,), "b"
     yield "denoiser.final_proj.fc.weight", (D, d), "w"
-    yield "denoiser.final_proj.fc.bias", (D,), "b"
+    if getattr(cfg, "final_proj_bias", True):
+        yield "denoiser.final_proj.fc.bias", (D,), "b"
     if cfg.denoiser.pos == "learned":         # lcm/nn/transformer/factory.py:187-198 through denoisers/factory.py:143
         yield "denoiser.pos_encoder.weight", (cfg.max_seq_len, d), "pos"
     yield from _tower_shapes("denoiser", d, cfg.denoiser, cross=True, modulator=True)

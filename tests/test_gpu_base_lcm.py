@@ -260,3 +260,36 @@ def test_base_layer_orders_forward_and_generation(order, final, pos):
     m16.load_state_dict(sd)
     out16 = m16.predict_next_sentence(EmbeddingsBatch(x.cuda().bfloat16(), None)).seqs.float().cpu()
     assert torch.nn.functional.cosine_similarity(out16, ref16, dim=-1).min() >= BF16_COS
+
+
+@pytest.mark.parametrize("act", ["tanh", "gelu"])
+def test_base_postnet_activation(act):
+    """`postnet.activation_name` (lcm/nn/projection.py:73-86): the activation follows the output projection, before the
+    sampling noise and the denormalization; forward over all positions and cached generation, fp32."""
+    from lcm.datasets.batch import EmbeddingsBatch
+    from lcm.models.base_lcm import create_base_lcm_model
+    from oracle.weights import synthetic_noise, synthetic_prompts
+    arch = "mini_base_lcm"
+    cfg = oracle.get_base_arch(arch)
+    cfg.postnet_activation = act
+    sd = oracle.init_state_dict(cfg, seed=6, qk_gain=2.0, w_std=0.05)
+    mc = base_config(arch)
+    mc.postnet.activation_name = act
+    model = create_base_lcm_model(mc, device="cuda:0", dtype=torch.float32)
+    model.load_state_dict(sd)
+    x = synthetic_prompts(oracle.load_dummy_normalizer(), 4, 30, seed=97)
+    ref = oracle.OracleBaseLCM(cfg, sd).predict(x)
+    out = model.predict_next_sentence(EmbeddingsBatch(x.cuda(), None)).seqs.cpu()
+    assert (out - ref).abs().max() <= 2e-4 * ref.abs().max()
+    cfg.postnet_activation = None
+    assert (out - oracle.OracleBaseLCM(cfg, sd).predict(x)).abs().max() > 1e-2 * ref.abs().max()   # it matters here
+    cfg.postnet_activation = act
+    nz = synthetic_noise(8, 4, seed=98)
+    opts = dict(OPTS, lcm_temperature=0.5)
+    ref_g = run_oracle_base(cfg, sd, x[:, :4], nz, 4, opts)
+    out_g, _ = run_hip_base(arch, sd, x[:, :4], nz, 4, opts, model=model)
+    worst, cos = compare(out_g.hypotheses, ref_g, _norm_sd(sd), start=4)
+    assert worst <= FP32_MAX_ABS and cos >= FP32_COS, (worst, cos)
+    mc.postnet.activation_name = "prelu"
+    with pytest.raises(NotImplementedError):
+        create_base_lcm_model(mc, device="cuda:0", dtype=torch.float32)

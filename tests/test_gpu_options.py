@@ -436,3 +436,31 @@ def test_denoiser_options_the_reference_ignores_or_refuses():
     mc.denoiser.scale_residual, mc.denoiser.final_norm_order_style = 0.5, "post"
     model = create_two_tower_diffusion_lcm_model(mc, device="cuda:0", dtype=torch.float32)
     assert set(model.state_dict()) == set(create_two_tower_diffusion_lcm_model(mini_config(), device="cuda:0", dtype=torch.float32).state_dict())
+
+
+def test_projections_without_bias():
+    """frontend.pre_linear_bias / denoiser.pre_denoiser.linear_bias / post_denoiser.linear_bias = False
+    (two_tower_diffusion_lcm/frontend.py:24-36, lcm/nn/projection.py:28): the state dict has no such tensors and the
+    projections add nothing; an activation on the denoiser's projections is refused, not ignored."""
+    cfg = O.get_arch(ARCH)
+    cfg.frontend_bias = cfg.initial_proj_bias = cfg.final_proj_bias = False
+    sd = O.init_state_dict(cfg, seed=12, mod_gain=4.0, qk_gain=1.5)
+    assert not any(k in sd for k in ("encoder_frontend.pre_linear.bias", "denoiser.initial_proj.fc.bias", "denoiser.final_proj.fc.bias"))
+    from oracle.weights import synthetic_noise, synthetic_prompts
+    nrm = {"center": sd["sonar_normalizer.center"], "scale": sd["sonar_normalizer.scale"]}
+    x, nz = synthetic_prompts(nrm, 3, 4, seed=39), synthetic_noise(6, 3, seed=40)
+    opts = dict(DEFAULT_OPTS, inference_timesteps=10, guidance_scale=2.0)
+    ref = run_oracle(cfg, sd, x, nz, 2, opts)
+    from lcm.models.two_tower_diffusion_lcm import create_two_tower_diffusion_lcm_model
+    mc = mini_config()
+    mc.frontend.pre_linear_bias = mc.denoiser.pre_denoiser.linear_bias = mc.denoiser.post_denoiser.linear_bias = False
+    model = create_two_tower_diffusion_lcm_model(mc, device="cuda:0", dtype=torch.float32)
+    assert set(model.state_dict()) == set(sd)
+    model.load_state_dict(sd)
+    out = _hip_generate(model, x, nz, 2, opts)
+    worst, cos = compare(out.hypotheses, ref, sd, start=4)
+    assert worst <= FP32_MAX_ABS and cos >= FP32_COS, (worst, cos)
+    mc = mini_config()
+    mc.denoiser.post_denoiser.activation_name = "gelu"
+    with pytest.raises(NotImplementedError):
+        create_two_tower_diffusion_lcm_model(mc, device="cuda:0", dtype=torch.float32)
