@@ -177,11 +177,12 @@ constexpr int kMaxSplits = 12;
 // Inner activation of the two-matrix FFN (LCMHIP_ACT_*): torch.nn.ReLU / Tanh / ELU / LeakyReLU / SELU / GELU (erf
 // form) / SiLU / Softsign / Sigmoid / Hardsigmoid with their default arguments, evaluated in fp32.  `kind` is
 // uniform over a launch.
-__device__ __forceinline__ float apply_act(float v, int kind) {
+// `slope`: negative-side factor of LeakyReLU (0.01) / PReLU (learned), see act_slope().
+__device__ __forceinline__ float apply_act(float v, int kind, float slope = 0.01f) {
     switch (kind) {
         case LCMHIP_ACT_TANH: return tanhf(v);
         case LCMHIP_ACT_ELU: return v > 0.f ? v : expm1f(v);
-        case LCMHIP_ACT_LEAKY_RELU: return v > 0.f ? v : 0.01f * v;
+        case LCMHIP_ACT_LEAKY_RELU: return v > 0.f ? v : slope * v;   // and PReLU: see act_kind()
         case LCMHIP_ACT_SELU: return 1.0507009873554804934193349852946f * (v > 0.f ? v : 1.6732632423543772848170429916717f * expm1f(v));
         case LCMHIP_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
         case LCMHIP_ACT_SILU: return v / (1.f + __expf(-v));
@@ -223,6 +224,7 @@ struct GemmArgs {
     int M, N, K;
     int epilogue;
     int act;                    // LCMHIP_ACT_* of the LCMHIP_EPI_RELU epilogue (0 = ReLU)
+    const void* act_slope;      // LCMHIP_ACT_PRELU: the learned slope (one element of the operand dtype)
     int dtype;
     // RESID only: rows [M, M + extra_rows) of `out` get gate[n] * extra_const[n] added
     int extra_rows; const float* extra_const;
@@ -243,6 +245,12 @@ struct GemmArgs {
     int stack_sel;              // set by the kernels: the matrix of the workgroup's tile
     int slab_through;           // set by the launcher: split-K slab stores are written through (store16_through)
 };
+// PReLU runs as LeakyReLU with its learned slope: act_kind() is the `kind` and act_slope() the `slope` of apply_act().
+__device__ __forceinline__ int act_kind(const GemmArgs& p) { return p.act == LCMHIP_ACT_PRELU ? LCMHIP_ACT_LEAKY_RELU : p.act; }
+template <typename T>
+__device__ __forceinline__ float act_slope(const GemmArgs& p) {
+    return p.act == LCMHIP_ACT_PRELU ? Elem<T>::load(reinterpret_cast<const T*>(p.act_slope)) : 0.01f;
+}
 // True when launch_gemm would run this stacked product as ONE launch of a many-row kernel (whose epilogue knows the
 // per-matrix switches above); otherwise it runs one product per matrix and the switches must not be set.
 bool gemm_stack_is_fused(const GemmArgs& a);

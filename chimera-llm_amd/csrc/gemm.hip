@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void k_splitk_finish(GemmArgs p, int splits) {
         } else {
             if constexpr (EPI == LCMHIP_EPI_RELU) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
+                for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], act_kind(p), act_slope<T>(p));
             }
             size_t oidx;
             if (p.out_rows == nullptr) oidx = (size_t)m * p.ldo + n;

@@ -90,6 +90,8 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& p, const f32x4 (&ac
     const int quad = 4 * (lane >> 4), frow = lane & 15;
     const T* bias = reinterpret_cast<const T*>(p.bias);
     const T* bias2 = reinterpret_cast<const T*>(p.bias2);
+    const float slope = EPI == LCMHIP_EPI_RELU ? act_slope<T>(p) : 0.f;
+    const int kind = act_kind(p);
     float bv[TNO][4], bv2[TNO][4];
 #pragma unroll
     for (int tn = 0; tn < TNO; ++tn)
@@ -116,7 +118,7 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& p, const f32x4 (&ac
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     v[r] = acc[tn][tm][r] + bv[tn][r];
-                    if constexpr (EPI == LCMHIP_EPI_RELU) v[r] = apply_act(v[r], p.act);
+                    if constexpr (EPI == LCMHIP_EPI_RELU) v[r] = apply_act(v[r], kind, slope);
                     if constexpr (DUAL) {
                         const float g = v[r];
                         v[r] = (acc[tn + TNW / 2][tm][r] + bv2[tn][r]) * (g / (1.f + __expf(-g)));

@@ -37,6 +37,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x4 (&a
     } else {
         const T* bias = reinterpret_cast<const T*>(p.bias);
         const T* bias2 = reinterpret_cast<const T*>(p.bias2);
+        const float slope = EPI == LCMHIP_EPI_RELU ? act_slope<T>(p) : 0.f;
+        const int kind = act_kind(p);
         constexpr int TNO = DUAL ? TN / 2 : TN;   // output column tiles per wave
 #pragma unroll
         for (int tn = 0; tn < TNO; ++tn) {
@@ -87,7 +89,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x4 (&a
                     if (m >= p.M) continue;
                     if constexpr (EPI == LCMHIP_EPI_RELU) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
+                        for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], kind, slope);
                     }
                     if constexpr (DUAL) {
 #pragma unroll

@@ -101,7 +101,7 @@ struct Tensor {
 struct Lin { const void* w = nullptr; const void* b = nullptr; int out = 0, in = 0; };
 struct NormW { const void* w = nullptr; const void* b = nullptr; };
 struct AttnW { Lin q, k, v, o; NormW qn, kn; };   // qn / kn: optional q / k LayerNorm (attention.py:143-199)
-struct FfnW { Lin gate, inner, out; };
+struct FfnW { Lin gate, inner, out; const void* act_slope = nullptr; };   // act_slope: PReLU's learned slope
 struct CtxLayer {
     NormW sa_norm, ffn_norm;
     AttnW sa;
@@ -190,6 +190,8 @@ static int get_ffn(lcmhip_model* m, const std::string& p, int d, const lcmhip_to
     if (t.ffn_kind == LCMHIP_FFN_SWIGLU) LCM_TRY(get_lin(m, p + ".gate_proj", t.ffn_dim, d, true, &f->gate));
     LCM_TRY(get_lin(m, p + ".inner_proj", t.ffn_dim, d, true, &f->inner));
     LCM_TRY(get_lin(m, p + ".output_proj", d, t.ffn_dim, true, &f->out));
+    f->act_slope = nullptr;   // torch.nn.PReLU() as the inner activation module: one learned slope
+    if (t.ffn_kind == LCMHIP_FFN_RELU && t.ffn_activation == LCMHIP_ACT_PRELU) LCM_TRY(get_vec(m, p + ".inner_activation.weight", 1, &f->act_slope));
     return LCMHIP_OK;
 }
 
@@ -200,7 +202,7 @@ static int check_tower(const lcmhip_tower_desc& t, int d, const char* which) {
     LCM_REQUIRE(t.ffn_dim % 128 == 0, std::string(which) + ": ffn_dim must be a multiple of 128");
     LCM_REQUIRE(t.norm_kind >= LCMHIP_NORM_LAYERNORM && t.norm_kind <= LCMHIP_NORM_UNIT, "unknown norm kind");
     LCM_REQUIRE(t.ffn_kind == LCMHIP_FFN_RELU || t.ffn_kind == LCMHIP_FFN_SWIGLU, "unknown ffn kind");
-    LCM_REQUIRE(t.ffn_activation >= LCMHIP_ACT_RELU && t.ffn_activation <= LCMHIP_ACT_HARDSIGMOID, "unknown ffn activation");
+    LCM_REQUIRE(t.ffn_activation >= LCMHIP_ACT_RELU && t.ffn_activation <= LCMHIP_ACT_PRELU, "unknown ffn activation");
     LCM_REQUIRE(t.pos_kind >= LCMHIP_POS_NONE && t.pos_kind <= LCMHIP_POS_SINE, "unknown position kind");
     LCM_REQUIRE(t.norm_order >= LCMHIP_ORDER_PRE && t.norm_order <= LCMHIP_ORDER_NORMFORMER, "unknown norm order");
     LCM_REQUIRE((t.no_final_norm | 1) == 1 && (t.scale_residual | 1) == 1, std::string(which) + ": no_final_norm / scale_residual are 0 or 1");
@@ -478,10 +480,12 @@ static void gemm_cost(const GemmArgs& a, double out_es, double* bytes, double* f
 static int gemm(lcmhip_session* s, const char* tag, const void* A, int lda, const Lin& W, const Lin* W2,
                 const float* gate, void* out, int ldo, int M, int epi, hipStream_t st,
                 const int32_t* out_rows = nullptr, int extra_rows = 0, const float* extra_const = nullptr,
-                int out_head_cap = 0, const RowSteps* gate_steps = nullptr, int act = LCMHIP_ACT_RELU) {
+                int out_head_cap = 0, const RowSteps* gate_steps = nullptr, int act = LCMHIP_ACT_RELU,
+                const void* act_slope = nullptr) {
     GemmArgs a = gemm_args(s, A, lda, W, W2, M, epi);
     a.gate = gate;
     a.act = act;
+    a.act_slope = act_slope;
     if (gate_steps && gate_steps->row_step) {
         a.gate_rows = gate_steps->row_step; a.gate_stride = gate_steps->step_stride; a.gate_steps = gate_steps->n_steps;
     }
@@ -605,7 +609,7 @@ static int ffn_in(lcmhip_session* s, const char* tag, const lcmhip_tower_desc& t
     if (t.ffn_kind == LCMHIP_FFN_SWIGLU)
         return gemm(s, tag, a, d, f.gate, &f.inner, nullptr, s->act_h, t.ffn_dim, rows, LCMHIP_EPI_SWIGLU, st);
     return gemm(s, tag, a, d, f.inner, nullptr, nullptr, s->act_h, t.ffn_dim, rows, LCMHIP_EPI_RELU, st, nullptr, 0, nullptr, 0,
-                nullptr, t.ffn_activation);
+                nullptr, t.ffn_activation, f.act_slope);
 }
 
 }  // namespace lcmhip

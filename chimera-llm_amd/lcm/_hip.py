@@ -19,7 +19,7 @@ NORM_LAYERNORM, NORM_RMS, NORM_FP32, NORM_UNIT = 0, 1, 2, 3
 FFN_RELU, FFN_SWIGLU = 0, 1
 # LCMHIP_ACT_*: inner activation of the two-matrix FFN, by the reference's name (lcm/nn/initialization.py:121-151)
 ACT = {"relu": 0, "tanh": 1, "elu": 2, "leaky_relu": 3, "selu": 4, "gelu": 5, "silu": 6, "softsign": 7, "sigmoid": 8,
-       "hardsigmoid": 9}
+       "hardsigmoid": 9, "prelu": 10}   # prelu: an FFN's inner activation only (its slope is a tensor of the layer)
 POS_NONE, POS_LEARNED, POS_ROPE, POS_SINE = 0, 1, 2, 3
 ORDER = {"pre": 0, "post": 1, "normformer": 2}   # LCMHIP_ORDER_*
 PRED = {"sample": 0, "epsilon": 1, "v_prediction": 2}

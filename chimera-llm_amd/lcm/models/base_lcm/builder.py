@@ -29,6 +29,7 @@ from lcm.models.two_tower_diffusion_lcm.builder import (
     final_norm_absent,
     normalizer_config_for,
     normalizer_spec,
+    prelu_spec,
     tower_desc,
 )
 from lcm.nn.incremental_state import LCMIncrementalStateBag
@@ -106,6 +107,7 @@ def parameter_spec(config: BaseLCModelConfig,
         spec.append((f"{p}.ffn.inner_proj.bias", (F,), "zeros"))
         spec.append((f"{p}.ffn.output_proj.weight", (d, F), "matrix"))
         spec.append((f"{p}.ffn.output_proj.bias", (d,), "zeros"))
+        prelu_spec(spec, p, tc)
         extra_layer_spec(spec, p, tc, d, norm)
     if not final_norm_absent(tc):
         norm("lcm.layer_norm")
@@ -136,7 +138,8 @@ class BaseLCModel(AbstractLCModel):
         _check_supported("lcm", config.lcm)
         if config.model_output_dim not in (None, config.sonar_embed_dim):
             raise NotImplementedError("model_output_dim other than the SONAR dimension is not implemented on the HIP path")
-        if config.postnet.activation_name is not None and config.postnet.activation_name not in _hip.ACT:
+        if config.postnet.activation_name is not None and (config.postnet.activation_name not in _hip.ACT
+                                                           or config.postnet.activation_name == "prelu"):
             # "prelu" carries a learned slope; anything else is unknown to the reference too (initialization.py:121-151)
             raise NotImplementedError(f"postnet activation {config.postnet.activation_name} is not implemented on the HIP path")
         self.model_dim = config.model_dim

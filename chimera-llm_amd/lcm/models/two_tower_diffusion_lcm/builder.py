@@ -81,8 +81,7 @@ def _check_supported(name: str, tc: TransformerConfig, denoiser: bool = False) -
             bad.append(f"norm order {tc.norm_order_style} / {tc.final_norm_order_style}")
         if tc.pos_embedding_style not in _POS_KIND:
             bad.append(f"pos_embedding_style={tc.pos_embedding_style}")
-    if not tc.use_swiglu and tc.ffn_inner_activation_name not in _hip.ACT:
-        # "prelu" carries a learned slope (a parameter of the activation module); anything else is unknown to the reference too
+    if not tc.use_swiglu and tc.ffn_inner_activation_name not in _hip.ACT:      # unknown to the reference too
         bad.append(f"ffn activation {tc.ffn_inner_activation_name}")
     if bad:
         raise NotImplementedError(f"{name}: not implemented on the HIP path: {', '.join(bad)}")
@@ -107,6 +106,13 @@ def extra_layer_spec(spec: list, p: str, tc: TransformerConfig, d: int, norm: Ca
             spec.append((f"{p}.ffn.inner_layer_norm.bias", (F,), "zeros"))
     if tc.scale_residual is not None:
         spec.append((f"{p}.residual_scale", (d,), f"const:{float(tc.scale_residual)}"))
+
+
+def prelu_spec(spec: list, p: str, tc: TransformerConfig) -> None:
+    """torch.nn.PReLU() as the two-matrix FFN's inner activation module (lcm/nn/initialization.py:135-136): one learned
+    slope, initialised at 0.25."""
+    if not tc.use_swiglu and tc.ffn_inner_activation_name == "prelu":
+        spec.append((f"{p}.ffn.inner_activation.weight", (1,), "const:0.25"))
 
 
 def tower_desc(tc: TransformerConfig, denoiser: bool = False) -> "_hip.TowerDesc":
@@ -195,6 +201,7 @@ def parameter_spec(config: TwoTowerDiffusionLCModelConfig,
             spec.append((f"{p}.ffn.inner_proj.bias", (F,), "zeros"))
             spec.append((f"{p}.ffn.output_proj.weight", (d, F), "matrix"))
             spec.append((f"{p}.ffn.output_proj.bias", (d,), "zeros"))
+            prelu_spec(spec, p, tc)
             if denoiser:
                 spec.append((f"{p}.modulator.fc.weight", (9 * d, d), "modulator"))
                 spec.append((f"{p}.modulator.fc.bias", (9 * d,), "modulator"))

@@ -29,7 +29,7 @@ extern "C" {
 
 /* Version of this ABI (struct layouts and signatures).  lcmhip_version() returns the value the library was built
  * with; a caller built against another value must not bind.  300 -> 400: lcmhip_tower_desc.norm_order,
- * no_final_norm and scale_residual, LCMHIP_POS_SINE, lcmhip_model_desc.postnet_activation; 200 -> 300: lcmhip_session_workspace_bytes and
+ * no_final_norm and scale_residual, LCMHIP_POS_SINE, LCMHIP_ACT_PRELU, lcmhip_model_desc.postnet_activation; 200 -> 300: lcmhip_session_workspace_bytes and
  * lcmhip_session_create take `flags`, lcmhip_static_init added, lcmhip_tower_desc.ffn_activation; 100 -> 200: lcmhip_tower_desc.qk_layernorm,
  * thresholding fields of lcmhip_denoise_params, variance_noise of lcmhip_ddim_cfg_step. */
 #define LCMHIP_ABI_VERSION 400
@@ -47,10 +47,13 @@ enum { LCMHIP_F32 = 0, LCMHIP_BF16 = 1 };
 enum { LCMHIP_NORM_LAYERNORM = 0, LCMHIP_NORM_RMS = 1, LCMHIP_NORM_FP32 = 2, LCMHIP_NORM_UNIT = 3 };
 enum { LCMHIP_FFN_RELU = 0, LCMHIP_FFN_SWIGLU = 1 };  /* FFN_RELU: the two-matrix FFN with the activation of ffn_activation */
 /* Inner activation of the two-matrix FFN (lcm/nn/transformer/factory.py:73, lcm/nn/initialization.py:121-151: the
- * torch.nn modules of these names with their default arguments).  "prelu" has a learned slope and is not offered. */
+ * torch.nn modules of these names with their default arguments).  PRELU (torch.nn.PReLU(): one learned slope, tensor
+ * <layer>.ffn.inner_activation.weight of shape (1,)) exists as lcmhip_tower_desc.ffn_activation only: the epilogue
+ * argument of lcmhip_gemm has no room for the slope. */
 enum {
     LCMHIP_ACT_RELU = 0, LCMHIP_ACT_TANH = 1, LCMHIP_ACT_ELU = 2, LCMHIP_ACT_LEAKY_RELU = 3, LCMHIP_ACT_SELU = 4,
-    LCMHIP_ACT_GELU = 5, LCMHIP_ACT_SILU = 6, LCMHIP_ACT_SOFTSIGN = 7, LCMHIP_ACT_SIGMOID = 8, LCMHIP_ACT_HARDSIGMOID = 9
+    LCMHIP_ACT_GELU = 5, LCMHIP_ACT_SILU = 6, LCMHIP_ACT_SOFTSIGN = 7, LCMHIP_ACT_SIGMOID = 8, LCMHIP_ACT_HARDSIGMOID = 9,
+    LCMHIP_ACT_PRELU = 10
 };
 /* lcm/nn/transformer/factory.py:79-87.  SINE: fairseq2's SinusoidalPositionEncoder, added by the frontend in fp32 --
  * row p = [sin(p f_0) .. sin(p f_{h-1}), cos(p f_0) .. cos(p f_{h-1})], h = model_dim / 2, f_i = exp(-i ln(10000) / (h - 1));

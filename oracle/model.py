@@ -216,7 +216,11 @@ class OracleTwoTower:
         if tc.use_swiglu:   # fairseq2 GLUFeedForwardNetwork: output(inner(x) * silu(gate(x)))
             return linear(linear(x, sd, prefix + ".inner_proj") * F.silu(linear(x, sd, prefix + ".gate_proj")),
                           sd, prefix + ".output_proj")
-        h = ACTIVATIONS[tc.activation](linear(x, sd, prefix + ".inner_proj"))
+        h = linear(x, sd, prefix + ".inner_proj")
+        if tc.activation == "prelu":      # torch.nn.PReLU(): one learned slope, a parameter of the activation module
+            h = F.prelu(h, sd[prefix + ".inner_activation.weight"])
+        else:
+            h = ACTIVATIONS[tc.activation](h)
         if prefix + ".inner_layer_norm.weight" in sd:
             # fairseq2 StandardFeedForwardNetwork built with the normformer order (factory.py:292-300): its default
             # LayerNorm (weight + bias) on the inner activations, before the output projection

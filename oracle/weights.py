@@ -75,6 +75,8 @@ def _tower_shapes(prefix: str, d: int, tc: TowerConfig, cross: bool, modulator: 
         yield f"{p}.ffn.inner_proj.bias", (F,), "b"
         yield f"{p}.ffn.output_proj.weight", (d, F), "w"
         yield f"{p}.ffn.output_proj.bias", (d,), "b"
+        if not tc.use_swiglu and tc.activation == "prelu":
+            yield f"{p}.ffn.inner_activation.weight", (1,), "prelu"
         if modulator:
             yield f"{p}.modulator.fc.weight", (9 * d, d), "mod_w"
             yield f"{p}.modulator.fc.bias", (9 * d,), "mod_b"
@@ -192,6 +194,8 @@ def init_state_dict(cfg: ArchConfig, seed: int = 0, *, w_std: float = 0.02, b_st
             sd[name] = 1.0 + _normal(seed, name, shape, norm_jitter)
         elif kind == "norm_b":
             sd[name] = _normal(seed, name, shape, norm_jitter)
+        elif kind == "prelu":                 # away from PReLU's initial 0.25 and from LeakyReLU's 0.01
+            sd[name] = 0.4 + _normal(seed, name, shape, 0.05)
         elif kind == "res_scale":             # around 0.5, away from the neutral 1
             sd[name] = 0.5 + _normal(seed, name, shape, 0.1)
         else:

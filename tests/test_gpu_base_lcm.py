@@ -293,3 +293,28 @@ def test_base_postnet_activation(act):
     mc.postnet.activation_name = "prelu"
     with pytest.raises(NotImplementedError):
         create_base_lcm_model(mc, device="cuda:0", dtype=torch.float32)
+
+
+def test_base_prelu_many_rows_bf16():
+    """The PReLU epilogue of the many-row matrix-core kernels: toy base LCM (two-matrix FFN) forward over 4 x 160 rows
+    in bf16 and fp32 against the oracle."""
+    from lcm.datasets.batch import EmbeddingsBatch
+    from lcm.models.base_lcm import create_base_lcm_model, lcm_archs
+    from oracle.weights import synthetic_prompts
+    arch = "toy_base_lcm"
+    cfg = oracle.get_base_arch(arch)
+    cfg.lcm.activation = "prelu"
+    sd = oracle.init_state_dict(cfg, seed=9, qk_gain=2.0, pos_std=0.5)
+    mc = lcm_archs.get_config(arch)
+    mc.lcm.ffn_inner_activation_name = "prelu"
+    x = synthetic_prompts(oracle.load_dummy_normalizer(), 4, 160, seed=107) * 50.0
+    for dtype in (torch.float32, torch.bfloat16):
+        sdd = sd if dtype == torch.float32 else {k: v.bfloat16().float() for k, v in sd.items()}
+        xd = x if dtype == torch.float32 else x.bfloat16().float()
+        ref = oracle.OracleBaseLCM(cfg, sdd).predict(xd)
+        model = create_base_lcm_model(mc, device="cuda:0", dtype=dtype)
+        assert set(model.state_dict()) == set(sd)
+        model.load_state_dict(sd)
+        out = model.predict_next_sentence(EmbeddingsBatch(xd.cuda().to(dtype), None)).seqs.float().cpu()
+        cos = torch.nn.functional.cosine_similarity(out, ref, dim=-1).min()
+        assert cos >= (FP32_COS if dtype == torch.float32 else BF16_COS), (dtype, cos)

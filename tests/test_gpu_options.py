@@ -323,9 +323,44 @@ def test_ffn_inner_activation(act):
     assert worst <= 1e-3 and cos >= 0.9999, (act, worst, cos)
     relu = run_oracle(O.get_arch(arch), sd, x, nz, 2, opts)
     assert compare(out.hypotheses, relu, sd, start=3)[0] > 1e-2          # the activation is really in the path
-    mc.denoiser.ffn_inner_activation_name = "prelu"
+    mc.denoiser.ffn_inner_activation_name = "swish"                      # a name the reference does not know either
     with pytest.raises(NotImplementedError):
         create_two_tower_diffusion_lcm_model(mc, device="cuda:0", dtype=torch.float32)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_ffn_prelu(dtype):
+    """"prelu" as the inner activation (lcm/nn/initialization.py:135-136: torch.nn.PReLU(), one learned slope per FFN,
+    a tensor of the layer) in both towers of the toy arch; a new model starts at torch's 0.25."""
+    arch = "toy_two_tower_diffusion_lcm"
+    from lcm.models.two_tower_diffusion_lcm import create_two_tower_diffusion_lcm_model, lcm_archs
+    from oracle.weights import synthetic_noise, synthetic_prompts
+    cfg = O.get_arch(arch)
+    cfg.context.activation = cfg.denoiser.activation = "prelu"
+    sd = O.init_state_dict(cfg, seed=14, mod_gain=4.0, qk_gain=1.5, pos_std=0.5)
+    assert sd["denoiser.layers.1.ffn.inner_activation.weight"].shape == (1,)
+    nrm = {"center": sd["sonar_normalizer.center"], "scale": sd["sonar_normalizer.scale"]}
+    x, nz = synthetic_prompts(nrm, 3, 3, seed=49), synthetic_noise(5, 3, seed=50)
+    opts = dict(DEFAULT_OPTS, inference_timesteps=6)
+    if dtype == torch.bfloat16:
+        sd = {k: O.r16(v) for k, v in sd.items()}
+        x = O.r16(x)
+    ref = run_oracle(cfg, sd, x, nz, 2, opts)
+    mc = lcm_archs.get_config(arch)
+    mc.context_encoder.ffn_inner_activation_name = mc.denoiser.ffn_inner_activation_name = "prelu"
+    model = create_two_tower_diffusion_lcm_model(mc, device="cuda:0", dtype=dtype)
+    assert set(model.state_dict()) == set(sd)
+    assert float(model.state_dict()["context_encoder.layers.0.ffn.inner_activation.weight"]) == 0.25
+    model.load_state_dict(sd)
+    out = _hip_generate(model, x, nz, 2, opts)
+    worst, cos = compare(out.hypotheses, ref, sd, start=3)
+    if dtype == torch.float32:
+        assert worst <= FP32_MAX_ABS and cos >= FP32_COS, (worst, cos)
+        cfg.context.activation = cfg.denoiser.activation = "leaky_relu"   # the learned slope, not LeakyReLU's 0.01
+        leaky = run_oracle(cfg, sd, x, nz, 2, opts)
+        assert compare(out.hypotheses, leaky, sd, start=3)[0] > 10 * FP32_MAX_ABS
+    else:
+        assert cos >= BF16_COS, (worst, cos)
 
 
 def test_weight_normalized_checkpoint():
