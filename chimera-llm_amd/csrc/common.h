@@ -296,6 +296,8 @@ struct KeyWindow {
 int launch_normalize(const void* x, const void* center, const void* scale, const void* cmin, const void* cmax,
                      void* y, int64_t rows, int dim, int dtype, bool inverse, hipStream_t st);
 // fp32 in -> T out, used by the frontend: y = (x - center) / scale with T-typed center/scale.
+// Packed real FFT of every row (dim a power of two, 64 .. 4096) and its inverse; see lcmhip_rfft_pack.
+int launch_rfft_pack(const float* x, float* y, int64_t rows, int dim, int inverse, hipStream_t st);
 int launch_normalize_f32_in(const float* x, const void* center, const void* scale, void* y, int64_t rows, int dim,
                             int dtype, hipStream_t st);
 // Rows [0, rows_norm) are normalised (+ modulated) into y; when `pend` is given, rows [0, rows_total)

@@ -1413,6 +1413,69 @@ int launch_scale_cols(float* x, const void* scale, int rows, int d, int dtype, h
     return LCMHIP_OK;
 }
 
+// Real FFT of one row per workgroup, packed like the reference's FFTInterface (sonar_normalizer/builder.py:58-84):
+// forward = torch.fft.rfft(x, norm="backward") as [Re X_0 .. Re X_{n/2}, Im X_1 .. Im X_{n/2-1}]; inverse = torch.fft.irfft
+// of that packing with Im X_0 = Im X_{n/2} = 0.  A radix-2 decimation-in-time transform of n complex points in LDS
+// (bit-reversed load, log2 n stages of n / 2 butterflies, twiddles e^{-+2 pi i k / n} from sincospif into LDS once per
+// workgroup); the inverse runs the conjugate transform on the Hermitian extension and keeps the real parts / n.  A
+// normalizer transform of a few rows per sentence: written for exactness, not speed.
+template <bool INV>
+__global__ __launch_bounds__(256) void k_rfft_pack(const float* x, float* y, int n, int logn) {   // y may be x
+    extern __shared__ float2 fft_lds[];
+    float2* a = fft_lds;
+    float2* tw = fft_lds + n;
+    const int tid = threadIdx.x, h = n / 2;
+    const float* xr = x + (size_t)blockIdx.x * n;
+    float* yr = y + (size_t)blockIdx.x * n;
+    for (int k = tid; k < h; k += 256) {
+        float sn, cs;
+        sincospif(2.f * (float)k / (float)n, &sn, &cs);
+        tw[k] = make_float2(cs, INV ? sn : -sn);
+    }
+    for (int i = tid; i < n; i += 256) {
+        float2 v;
+        if (!INV) {
+            v = make_float2(xr[i], 0.f);
+        } else {   // X_i for i <= n/2, conj(X_{n-i}) above
+            const int k = i <= h ? i : n - i;
+            const float im = (k == 0 || k == h) ? 0.f : xr[h + k];
+            v = make_float2(xr[k], i <= h ? im : -im);
+        }
+        a[__brev((unsigned)i) >> (32 - logn)] = v;
+    }
+    __syncthreads();
+    for (int s = 1; s <= logn; ++s) {
+        const int half = 1 << (s - 1);
+        for (int j = tid; j < h; j += 256) {
+            const int pos = j & (half - 1);
+            const int i0 = ((j >> (s - 1)) << s) + pos, i1 = i0 + half;
+            const float2 w = tw[pos << (logn - s)], b = a[i1], u = a[i0];
+            const float2 t = make_float2(w.x * b.x - w.y * b.y, w.x * b.y + w.y * b.x);
+            a[i0] = make_float2(u.x + t.x, u.y + t.y);
+            a[i1] = make_float2(u.x - t.x, u.y - t.y);
+        }
+        __syncthreads();
+    }
+    const float inv_n = 1.f / (float)n;
+    for (int i = tid; i < n; i += 256) {
+        if (!INV) yr[i] = i <= h ? a[i].x : a[i - h].y;
+        else yr[i] = a[i].x * inv_n;
+    }
+}
+
+int launch_rfft_pack(const float* x, float* y, int64_t rows, int dim, int inverse, hipStream_t st) {
+    LCM_REQUIRE(dim >= 64 && dim <= 4096 && (dim & (dim - 1)) == 0, "rfft: dim must be a power of two in [64, 4096]");
+    LCM_REQUIRE(rows >= 0 && rows <= 0x7fffffff, "rfft: bad row count");
+    if (rows == 0) return LCMHIP_OK;
+    int logn = 0;
+    while ((1 << logn) < dim) ++logn;
+    const size_t lds = (size_t)dim * 12;   // n points + n / 2 twiddles, 8 bytes each
+    if (inverse) hipLaunchKernelGGL((k_rfft_pack<true>), dim3((unsigned)rows), dim3(256), lds, st, x, y, dim, logn);
+    else hipLaunchKernelGGL((k_rfft_pack<false>), dim3((unsigned)rows), dim3(256), lds, st, x, y, dim, logn);
+    LCM_HIP_CHECK(hipGetLastError());
+    return LCMHIP_OK;
+}
+
 // cache[rows_idx[i]][:] = vec[:]   (vec null: zeros)
 template <typename T>
 __global__ __launch_bounds__(256) void k_fill_rows(T* __restrict__ cache, const T* __restrict__ vec,

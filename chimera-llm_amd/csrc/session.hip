@@ -1468,6 +1468,11 @@ int lcmhip_denormalize(const void* x, const void* center, const void* scale, con
     return launch_normalize(x, center, scale, clip_min, clip_max, y, rows, dim, dtype, true, static_cast<hipStream_t>(stream));
 }
 
+int lcmhip_rfft_pack(const float* x, float* y, int64_t rows, int32_t dim, int32_t inverse, void* stream) {
+    LCM_REQUIRE(x && y, "rfft_pack: null argument");
+    return launch_rfft_pack(x, y, rows, dim, inverse != 0, static_cast<hipStream_t>(stream));
+}
+
 int lcmhip_norm_modulate(const float* x, const void* weight, const void* bias, const float* shift, const float* scale,
                          void* y, int32_t rows, int32_t dim, int32_t norm_kind, float eps, int32_t dtype, void* stream) {
     LCM_REQUIRE(x && y, "norm_modulate: null argument");

@@ -37,7 +37,7 @@ EXPORTS = [
     "lcmhip_denoise_positions",
     "lcmhip_session_reorder", "lcmhip_session_context_len", "lcmhip_session_num_active",
     "lcmhip_session_read_context", "lcmhip_session_profile_enable", "lcmhip_session_profile",
-    "lcmhip_normalize", "lcmhip_denormalize", "lcmhip_norm_modulate", "lcmhip_gemm", "lcmhip_static_init", "lcmhip_gemm_static", "lcmhip_gemm_partial",
+    "lcmhip_normalize", "lcmhip_denormalize", "lcmhip_rfft_pack", "lcmhip_norm_modulate", "lcmhip_gemm", "lcmhip_static_init", "lcmhip_gemm_static", "lcmhip_gemm_partial",
     "lcmhip_residual_norm",
     "lcmhip_ddim_cfg_step", "lcmhip_attention", "lcmhip_finalize_step", "lcmhip_stream_copy",
 ]
@@ -107,6 +107,7 @@ def _load() -> C.CDLL:
         "lcmhip_session_profile": [vp, C.POINTER(ProfileRow), i32, C.POINTER(i32), vp],
         "lcmhip_normalize": [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp],
         "lcmhip_denormalize": [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp],
+        "lcmhip_rfft_pack": [vp, vp, i64, i32, i32, vp],
         "lcmhip_norm_modulate": [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp],
         "lcmhip_gemm": [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, C.c_size_t, vp],
         "lcmhip_static_init": [],
@@ -152,6 +153,17 @@ def ptr(t) -> C.c_void_p:
 
 def stream_ptr(device=None) -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def rfft_pack(x: torch.Tensor, inverse: bool) -> torch.Tensor:
+    """The packed real FFT a with_fft normalizer applies to raw embeddings (and its inverse), over the last dimension,
+    in fp32 (reference sonar_normalizer/builder.py:58-84 computes it in fp32 for half-precision inputs too)."""
+    require_gpu(x, "embeddings")
+    x32 = x.float().contiguous()
+    y = torch.empty_like(x32)
+    dim = x32.shape[-1]
+    check(lib.lcmhip_rfft_pack(ptr(x32), ptr(y), x32.numel() // dim, dim, int(inverse), stream_ptr(x.device)))
+    return y
 
 
 def require_gpu(t: torch.Tensor, what: str) -> None:

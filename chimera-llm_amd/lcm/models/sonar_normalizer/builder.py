@@ -29,7 +29,6 @@ sonar_normalizer_archs: Dict[str, SonarNormalizerConfig] = {
     "base": SonarNormalizerConfig(),
     "base_page4k": SonarNormalizerConfig(dim=4 * 1024),
     "clipping": SonarNormalizerConfig(clip_proba=1e-4),
-    # registered so that a card naming them is refused with a clear message instead of an unknown-arch error
     "base_fft": SonarNormalizerConfig(with_fft=True),
     "clipping_fft": SonarNormalizerConfig(clip_proba=1e-4, with_fft=True),
 }
@@ -37,8 +36,6 @@ sonar_normalizer_archs: Dict[str, SonarNormalizerConfig] = {
 
 class SonarNormalizer:
     def __init__(self, config: SonarNormalizerConfig, device=None, dtype: Optional[torch.dtype] = None) -> None:
-        if config.with_fft:
-            raise NotImplementedError("FFT normalizer variants are outside the generation path")
         self.config = config
         dtype = dtype or torch.float32
         self.center = torch.zeros(config.dim, dtype=dtype, device=device)
@@ -72,10 +69,15 @@ class SonarNormalizer:
         return y
 
     def normalize(self, embeddings: Tensor) -> Tensor:
+        if self.config.with_fft:        # builder.py:121-128: the transform precedes center / scale / clip
+            embeddings = _hip.rfft_pack(embeddings, inverse=False)
         return self._run(embeddings, _hip.lib.lcmhip_normalize)
 
     def denormalize(self, embeddings: Tensor) -> Tensor:
-        return self._run(embeddings, _hip.lib.lcmhip_denormalize)
+        y = self._run(embeddings, _hip.lib.lcmhip_denormalize)
+        if self.config.with_fft:        # builder.py:130-137: and its inverse follows them
+            y = _hip.rfft_pack(y, inverse=True).to(y.dtype)
+        return y
 
     def fit(self, embeddings: Tensor):
         raise NotImplementedError("fitting a normalizer is outside the generation path")

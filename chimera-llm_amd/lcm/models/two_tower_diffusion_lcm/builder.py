@@ -143,8 +143,6 @@ def normalizer_config_for(name: Optional[str], dim: int) -> SonarNormalizerConfi
         if card is not None:
             arch = sonar_normalizer_archs[card.get("model_arch", "base")]
             cfg = SonarNormalizerConfig(**{**arch.__dict__, "dim": dim})
-    if cfg.with_fft:
-        raise NotImplementedError("FFT normalizer variants are not implemented on the HIP path")
     return cfg
 
 
@@ -291,10 +289,23 @@ class DeviceSession:
     def reset(self, n_docs: int) -> None:
         _hip.check(_hip.lib.lcmhip_session_reset(self._h, n_docs, self._stream()))
 
+    # A with_fft normalizer (sonar_normalizer/builder.py:121-137) transforms raw embeddings before center / scale / clip
+    # and transforms back after them.  The library's fused normalize / denormalize steps do the center / scale / clip
+    # part; the transform itself (lcmhip_rfft_pack) runs here, on the way in and on the way out.
+    def _with_fft(self) -> bool:
+        n = getattr(self.model, "sonar_normalizer", None)
+        return n is not None and n.config.with_fft
+
+    def _to_model_space(self, x32: Tensor, normalized: bool) -> Tensor:
+        return _hip.rfft_pack(x32, inverse=False) if (not normalized and self._with_fft()) else x32
+
+    def _from_model_space(self, out: Optional[Tensor]) -> Optional[Tensor]:
+        return _hip.rfft_pack(out, inverse=True) if (out is not None and self._with_fft()) else out
+
     def append(self, x: Tensor, normalized: bool) -> None:
         """x: (n_active, s, D) embeddings of the next s context positions."""
         _hip.require_gpu(x, "context embeddings")
-        x32 = x.float().contiguous()
+        x32 = self._to_model_space(x.float().contiguous(), normalized)
         assert x32.dim() == 3 and x32.shape[0] == self.num_active, (tuple(x32.shape), self.num_active)
         _hip.check(_hip.lib.lcmhip_context_append(self._h, _hip.ptr(x32), x32.shape[1], int(normalized), self._stream()))
 
@@ -303,7 +314,7 @@ class DeviceSession:
         """Base LCM: appends the s positions of x (n_active, s, D) and returns the predictions, fp32, for every
         position (n_active, s, D) or for the last one (n_active, D); None when only the cache is wanted."""
         _hip.require_gpu(x, "input embeddings")
-        x32 = x.float().contiguous()
+        x32 = self._to_model_space(x.float().contiguous(), normalized)
         assert x32.dim() == 3 and x32.shape[0] == self.num_active, (tuple(x32.shape), self.num_active)
         out = None
         if want_output:
@@ -315,7 +326,7 @@ class DeviceSession:
             assert nz.numel() == out.numel(), "noise must have the shape of the output"
         _hip.check(_hip.lib.lcmhip_base_forward(self._h, _hip.ptr(x32), x32.shape[1], int(normalized), _hip.ptr(nz),
                                                 float(temperature), int(all_positions), _hip.ptr(out), self._stream()))
-        return out
+        return self._from_model_space(out)
 
     def denoise(self, noise: Tensor, trace: Optional[Tensor] = None, variance_noise: Optional[Tensor] = None) -> Tensor:
         """noise: (n_active, D) N(0, 1) draws -> next sentence embedding (n_active, D) fp32.  `variance_noise`
@@ -326,12 +337,12 @@ class DeviceSession:
         out = torch.empty_like(nz)
         if variance_noise is None:
             _hip.check(_hip.lib.lcmhip_denoise(self._h, _hip.ptr(nz), _hip.ptr(out), _hip.ptr(trace), self._stream()))
-            return out
+            return self._from_model_space(out)
         vn = variance_noise.float().contiguous()
         assert vn.dim() == 3 and vn.shape[1:] == nz.shape, (tuple(vn.shape), tuple(nz.shape))
         _hip.check(_hip.lib.lcmhip_denoise_stochastic(self._h, _hip.ptr(nz), _hip.ptr(vn), _hip.ptr(out), _hip.ptr(trace),
                                                       self._stream()))
-        return out
+        return self._from_model_space(out)
 
     def denoise_positions(self, noisy: Tensor, step_index: Tensor, source_lengths: Optional[Tensor] = None,
                           context_lengths: Optional[Tensor] = None) -> Tensor:

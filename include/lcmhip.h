@@ -29,7 +29,8 @@ extern "C" {
 
 /* Version of this ABI (struct layouts and signatures).  lcmhip_version() returns the value the library was built
  * with; a caller built against another value must not bind.  300 -> 400: lcmhip_tower_desc.norm_order,
- * no_final_norm and scale_residual, LCMHIP_POS_SINE, LCMHIP_ACT_PRELU, lcmhip_model_desc.postnet_activation; 200 -> 300: lcmhip_session_workspace_bytes and
+ * no_final_norm and scale_residual, LCMHIP_POS_SINE, LCMHIP_ACT_PRELU, lcmhip_model_desc.postnet_activation,
+ * lcmhip_rfft_pack; 200 -> 300: lcmhip_session_workspace_bytes and
  * lcmhip_session_create take `flags`, lcmhip_static_init added, lcmhip_tower_desc.ffn_activation; 100 -> 200: lcmhip_tower_desc.qk_layernorm,
  * thresholding fields of lcmhip_denoise_params, variance_noise of lcmhip_ddim_cfg_step. */
 #define LCMHIP_ABI_VERSION 400
@@ -287,6 +288,13 @@ int lcmhip_normalize(const void* x, const void* center, const void* scale, const
 int lcmhip_denormalize(const void* x, const void* center, const void* scale, const void* clip_min,
                        const void* clip_max, void* y, int64_t rows, int32_t dim, int32_t dtype,
                        void* stream);
+
+/* FFTInterface.fft_transform / fft_inverse_transform of the "base_fft" / "clipping_fft" normalizers
+ * (lcm/models/sonar_normalizer/builder.py:58-84, archs.py:28-40): the transform a with_fft normalizer applies to the raw
+ * embeddings before center / scale / clip, and its inverse after them.  x, y: (rows, dim) fp32, dim a power of two in
+ * [64, 4096]; y may equal x.  Forward (inverse = 0): X = rfft(x) without scaling, packed as
+ * [Re X_0 .. Re X_{dim/2}, Im X_1 .. Im X_{dim/2-1}]; inverse (1): irfft of that packing (Im X_0 = Im X_{dim/2} = 0). */
+int lcmhip_rfft_pack(const float* x, float* y, int64_t rows, int32_t dim, int32_t inverse, void* stream);
 
 /* Layer/RMS norm (lcm/nn/normalization.py:73-88) fused with the adaLN modulation
  * `h * (1 + scale) + shift` of lcm_denoiser.py:449-452.  x: (rows, dim) fp32; weight/bias:

@@ -66,6 +66,7 @@ class ArchConfig:
     scheduler: SchedulerConfig = field(default_factory=SchedulerConfig)
     trained_with_cf_guidance: bool = False
     sonar_normalizer_name: str = "dummy_sonar_normalizer"
+    normalizer_fft: bool = False           # the "base_fft" / "clipping_fft" normalizers (sonar_normalizer/archs.py:28-40)
     frontend_bias: bool = True             # two_tower_diffusion_lcm/frontend.py:24-36 pre_linear_bias
     initial_proj_bias: bool = True         # lcm/nn/projection.py:28 on denoiser.pre_denoiser / post_denoiser
     final_proj_bias: bool = True
@@ -111,6 +112,7 @@ class BaseArchConfig:
     pre_linear_bias: bool = True           # base_lcm/frontend.py:30
     postnet_bias: bool = True              # lcm/nn/projection.py:28
     postnet_activation: str = None         # lcm/nn/projection.py:37, 73-86
+    normalizer_fft: bool = False
     scale_embeddings: bool = False         # base_lcm/frontend.py:35, 91
     sonar_normalizer_name: str = None      # abstract_lcm/builder.py:33: no normalizer unless named
 

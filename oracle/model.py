@@ -102,6 +102,20 @@ def sdpa(q: Tensor, k: Tensor, v: Tensor, key_lens: Optional[Tensor], mask: Opti
     return torch.matmul(p, v.float()).type_as(q)
 
 
+def fft_transform(x: Tensor) -> Tensor:
+    """FFTInterface.fft_transform, lcm/models/sonar_normalizer/builder.py:59-67."""
+    X = torch.fft.rfft(x.float(), norm="backward")
+    return torch.cat([X.real, X.imag[..., 1:-1]], dim=-1).to(x.dtype)
+
+
+def fft_inverse_transform(y: Tensor) -> Tensor:
+    """FFTInterface.fft_inverse_transform, lcm/models/sonar_normalizer/builder.py:69-84."""
+    n = y.shape[-1]
+    rr, im = torch.split(y.float(), [n // 2 + 1, n // 2 - 1], dim=-1)
+    z = torch.zeros_like(im[..., :1])
+    return torch.fft.irfft(torch.complex(rr, torch.cat([z, im, z], dim=-1))).to(y.dtype)
+
+
 def sinusoidal_positions(start: int, n: int, dim: int) -> Tensor:
     """fairseq2 SinusoidalPositionEncoder as lcm/nn/transformer/factory.py:199-204 builds it (no legacy padding
     offset): an fp32 table, row p = [sin(p f_0) .. sin(p f_{h-1}), cos(p f_0) .. cos(p f_{h-1})] with h = dim / 2 and
@@ -170,6 +184,8 @@ class OracleTwoTower:
     # -- SONAR normalizer (lcm/models/sonar_normalizer/builder.py:121-137; clipping when the state dict holds
     #    clip_min / clip_max, i.e. the "clipping" arch; no fft)
     def normalize(self, x: Tensor) -> Tensor:
+        if getattr(self.cfg, "normalizer_fft", False):       # builder.py:121-123
+            x = fft_transform(x)
         y = (x - self.sd["sonar_normalizer.center"]) / self.sd["sonar_normalizer.scale"]
         if "sonar_normalizer.clip_min" in self.sd:
             y = torch.clamp(y, min=self.sd["sonar_normalizer.clip_min"], max=self.sd["sonar_normalizer.clip_max"])
@@ -178,7 +194,8 @@ class OracleTwoTower:
     def denormalize(self, x: Tensor) -> Tensor:
         if "sonar_normalizer.clip_min" in self.sd:
             x = torch.clamp(x, min=self.sd["sonar_normalizer.clip_min"], max=self.sd["sonar_normalizer.clip_max"])
-        return x * self.sd["sonar_normalizer.scale"] + self.sd["sonar_normalizer.center"]
+        y = x * self.sd["sonar_normalizer.scale"] + self.sd["sonar_normalizer.center"]
+        return fft_inverse_transform(y) if getattr(self.cfg, "normalizer_fft", False) else y   # builder.py:134-137
 
     # -- attention / ffn blocks
     def _mha(self, prefix: str, tc: TowerConfig, x_q: Tensor, x_kv: Tensor, *, key_lens=None, mask=None,
@@ -424,12 +441,15 @@ class OracleBaseLCM(OracleTwoTower):
     def normalize(self, x: Tensor) -> Tensor:
         if not self.has_normalizer:
             return x
+        if getattr(self.cfg, "normalizer_fft", False):
+            x = fft_transform(x)
         return (x - self.sd["frontend.sonar_normalizer.center"]) / self.sd["frontend.sonar_normalizer.scale"]
 
     def denormalize(self, x: Tensor) -> Tensor:
         if not self.has_normalizer:
             return x
-        return x * self.sd["frontend.sonar_normalizer.scale"] + self.sd["frontend.sonar_normalizer.center"]
+        y = x * self.sd["frontend.sonar_normalizer.scale"] + self.sd["frontend.sonar_normalizer.center"]
+        return fft_inverse_transform(y) if getattr(self.cfg, "normalizer_fft", False) else y
 
     def forward(self, x_norm: Tensor, cache: Optional[KVCache] = None) -> Tensor:
         """builder.py:94-124 on already-normalized inputs; `embed_scale` per frontend.py:91, 170."""

@@ -499,3 +499,74 @@ def test_projections_without_bias():
     mc.denoiser.post_denoiser.activation_name = "gelu"
     with pytest.raises(NotImplementedError):
         create_two_tower_diffusion_lcm_model(mc, device="cuda:0", dtype=torch.float32)
+
+
+@pytest.mark.parametrize("dim", [64, 1024, 4096])
+def test_rfft_pack_kernel(dim):
+    """lcmhip_rfft_pack against torch.fft in float64, packed as FFTInterface packs it
+    (lcm/models/sonar_normalizer/builder.py:58-84); forward, inverse, round trip, in place."""
+    from lcm import _hip
+    g = torch.Generator().manual_seed(dim)
+    x = torch.randn(37, dim, generator=g, dtype=torch.float32)
+    X = torch.fft.rfft(x.double())
+    want = torch.cat([X.real, X.imag[..., 1:-1]], dim=-1)
+    got = _hip.rfft_pack(x.cuda(), inverse=False)
+    assert (got.cpu().double() - want).abs().max() <= 2e-6 * want.abs().max()
+    back = _hip.rfft_pack(got, inverse=True)
+    assert (back.cpu() - x).abs().max() <= 5e-6 * x.abs().max()
+    y = torch.randn(5, dim, generator=g, dtype=torch.float32)              # any packed spectrum, not only a transform's
+    assert (_hip.rfft_pack(y.cuda(), inverse=True).cpu() - O.model.fft_inverse_transform(y)).abs().max() <= 5e-6 * y.abs().max()
+    buf = x.cuda().clone()
+    _hip.check(_hip.lib.lcmhip_rfft_pack(_hip.ptr(buf), _hip.ptr(buf), 37, dim, 0, _hip.stream_ptr(buf.device)))
+    assert torch.equal(buf, got)
+    with pytest.raises(RuntimeError):
+        _hip.rfft_pack(torch.zeros(2, 96, device="cuda:0"), inverse=False)
+
+
+@pytest.mark.parametrize("clip", [False, True])
+def test_fft_normalizer(tmp_path, clip):
+    """The "base_fft" / "clipping_fft" normalizer archs (lcm/models/sonar_normalizer/archs.py:28-40): the raw embeddings
+    pass through the packed real FFT before center / scale / clip and through its inverse after them, in the model's
+    own normalization (prefill, every generated sentence fed back, every output) and in the stand-alone normalizer."""
+    from lcm.models.two_tower_diffusion_lcm import create_two_tower_diffusion_lcm_model
+    from lcm.utils.card_utils import load_model_from_card, register_card
+    cfg, sd, x, nz = make_problem(ARCH, 3, 3, 2)
+    cfg.normalizer_fft = True
+    sd = dict(sd)
+    # statistics of the transformed embeddings: the spectrum of unit-variance rows has variance ~ dim / 2 per component
+    g = torch.Generator().manual_seed(7)
+    sd["sonar_normalizer.center"] = torch.randn(1024, generator=g)
+    sd["sonar_normalizer.scale"] = 20.0 + 5.0 * torch.rand(1024, generator=g)
+    x = torch.randn(3, 3, 1024, generator=g)
+    if clip:
+        sd["sonar_normalizer.clip_min"] = torch.full((1024,), -1.2) + 0.2 * torch.rand(1024, generator=g)
+        sd["sonar_normalizer.clip_max"] = torch.full((1024,), 1.3) - 0.2 * torch.rand(1024, generator=g)
+    arch = "clipping_fft" if clip else "base_fft"
+    ckpt = os.path.join(tmp_path, "fft_normalizer.pt")
+    torch.save({"model": {k.split(".", 1)[1]: v for k, v in sd.items() if k.startswith("sonar_normalizer.")}}, ckpt)
+    name = f"fft_test_normalizer_{int(clip)}"
+    register_card({"name": name, "model_family": "sonar_normalizer", "model_arch": arch, "checkpoint": "file://" + ckpt})
+    opts = dict(DEFAULT_OPTS, inference_timesteps=10, guidance_scale=2.0)
+    ref = run_oracle(cfg, sd, x, nz, 2, opts)
+    cfg.normalizer_fft = False
+    plain = run_oracle(cfg, sd, x, nz, 2, opts)
+    assert (ref[0][0].seq[3:] - plain[0][0].seq[3:]).abs().max() > 1e-2            # the transform matters here
+    mc = mini_config()
+    mc.sonar_normalizer_name = name
+    model = create_two_tower_diffusion_lcm_model(mc, device="cuda:0", dtype=torch.float32)
+    assert model.sonar_normalizer.config.with_fft and ("sonar_normalizer.clip_min" in model.state_dict()) == clip
+    model.load_state_dict(sd)
+    out = _hip_generate(model, x, nz, 2, opts)
+    # compared in the space of the raw embeddings, relative to their size
+    for hh, hr in zip(out.hypotheses, ref):
+        a, b = hh[0].seq.float().cpu()[3:], hr[0].seq[3:]
+        assert (a - b).abs().max() <= 1e-3 * b.abs().max(), float((a - b).abs().max() / b.abs().max())
+        assert torch.nn.functional.cosine_similarity(a, b, dim=-1).min() >= FP32_COS
+    n = load_model_from_card(name, device="cuda:0", dtype=torch.float32)
+    om = O.OracleTwoTower(O.get_arch(ARCH), sd)
+    om.cfg.normalizer_fft = True
+    want = om.normalize(x)
+    assert (n.normalize(x.cuda()).cpu() - want).abs().max() <= 1e-5 * max(1.0, float(want.abs().max()))
+    assert (model.sonar_normalizer.normalize(x.cuda()).cpu() - want).abs().max() <= 1e-5 * max(1.0, float(want.abs().max()))
+    back = n.denormalize(want.cuda()).cpu()
+    assert (back - om.denormalize(want)).abs().max() <= 1e-5 * max(1.0, float(x.abs().max()))

@@ -153,8 +153,8 @@ def test_norm_styles_and_clipping_normalizer_shape_the_parameter_table():
     assert normalizer_config_for(None, 1024) == SonarNormalizerConfig(dim=1024)
     register_card({"name": "host_test_fft_normalizer", "model_family": "sonar_normalizer", "model_arch": "base_fft",
                    "checkpoint": None})
-    with pytest.raises(NotImplementedError):
-        normalizer_config_for("host_test_fft_normalizer", 1024)
+    fcfg = normalizer_config_for("host_test_fft_normalizer", 1024)      # sonar_normalizer/archs.py:28-30
+    assert fcfg.with_fft and fcfg.clip_proba is None and fcfg.dim == 1024
 
 
 def test_qk_layernorm_adds_its_norms_to_the_parameter_table():
