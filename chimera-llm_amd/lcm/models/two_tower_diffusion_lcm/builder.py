@@ -9,6 +9,7 @@ like the reference's state dict; a `DeviceSession` owns the KV caches and scratc
 """
 
 import ctypes as C
+import math
 import logging
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional, Tuple
@@ -74,7 +75,7 @@ def _check_supported(name: str, tc: TransformerConfig, denoiser: bool = False) -
     if denoiser:
         if tc.norm_order_style != "pre":
             bad.append(f"norm_order_style={tc.norm_order_style} (denoiser layers are pre-norm)")
-        if tc.pos_embedding_style not in ("none", "learned"):
+        if tc.pos_embedding_style not in ("none", "learned", "sine"):
             bad.append(f"pos_embedding_style={tc.pos_embedding_style} on the denoiser")
     else:
         if tc.norm_order_style not in _hip.ORDER or tc.final_norm_order_style not in (None,) + tuple(_hip.ORDER):
@@ -108,6 +109,19 @@ def extra_layer_spec(spec: list, p: str, tc: TransformerConfig, d: int, norm: Ca
         spec.append((f"{p}.residual_scale", (d,), f"const:{float(tc.scale_residual)}"))
 
 
+def sinusoidal_table(n: int, dim: int, *, device, dtype) -> Tensor:
+    """fairseq2 SinusoidalPositionEncoder's table (as built at lcm/nn/transformer/factory.py:199-204): fp32 rows
+    [sin(p f_0) .. sin(p f_{h-1}), cos(p f_0) .. cos(p f_{h-1})], h = dim / 2, f_i = exp(-i ln(10000) / (h - 1)).  The
+    contextualizer adds these rows on the fly in fp32 (LCMHIP_POS_SINE); for the denoiser's latents (position 0 in the
+    sampling loop, position j in the all-positions forward) the table is handed to the library in the operand dtype, in
+    the place of learned positions -- a buffer of the module, not a state-dict entry, as in the reference."""
+    h = dim // 2
+    steps = torch.arange(n, dtype=torch.float32, device=device)
+    freqs = torch.exp(torch.arange(h, dtype=torch.float32, device=device) * (-math.log(10000.0) / (h - 1)))
+    ang = torch.outer(steps, freqs)
+    return torch.cat([ang.sin(), ang.cos()], dim=-1).to(dtype).contiguous()
+
+
 def prelu_spec(spec: list, p: str, tc: TransformerConfig) -> None:
     """torch.nn.PReLU() as the two-matrix FFN's inner activation module (lcm/nn/initialization.py:135-136): one learned
     slope, initialised at 0.25."""
@@ -121,7 +135,9 @@ def tower_desc(tc: TransformerConfig, denoiser: bool = False) -> "_hip.TowerDesc
         num_layers=tc.num_layers, num_heads=tc.num_attn_heads, ffn_dim=tc.allocated_ffn_dim(),
         norm_kind=_NORM_KIND[tc.layer_normalization_style],
         ffn_kind=_hip.FFN_SWIGLU if tc.use_swiglu else _hip.FFN_RELU,
-        pos_kind=_POS_KIND[tc.pos_embedding_style], out_proj_bias=int(tc.mha_output_proj_bias),
+        # the denoiser's sinusoidal positions reach the library as a table (see sinusoidal_table)
+        pos_kind=_hip.POS_LEARNED if denoiser and tc.pos_embedding_style == "sine" else _POS_KIND[tc.pos_embedding_style],
+        out_proj_bias=int(tc.mha_output_proj_bias),
         rope_theta=float(tc.rope_theta), qk_layernorm=int(tc.enable_qk_layernorm),
         ffn_activation=_hip.ACT.get(tc.ffn_inner_activation_name, 0),
         norm_order=0 if denoiser else _hip.ORDER[tc.norm_order_style],
@@ -453,6 +469,8 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
                         ("denoiser.final_proj.fc.bias", config.sonar_embed_dim)):
             if name not in self._params:
                 self._derived[name] = torch.zeros((n,), dtype=dtype, device=device)
+        if config.denoiser.pos_embedding_style == "sine":
+            self._derived["denoiser.pos_encoder.weight"] = sinusoidal_table(config.max_seq_len, d, device=device, dtype=dtype)
         self._handle = None
         self.init_parameters(seed if seed is not None else 0)
         self.sonar_normalizer = SonarNormalizer(ncfg, device=device, dtype=dtype)

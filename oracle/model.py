@@ -307,6 +307,8 @@ class OracleTwoTower:
         S = x.shape[1]
         if tc.pos == "learned":                                                      # :211-212, no state bag: from 0
             x = x + sd["denoiser.pos_encoder.weight"][:S]
+        elif tc.pos == "sine":                                                       # the same call with the sinusoidal encoder
+            x = (x.float() + sinusoidal_positions(0, S, x.shape[-1])).to(x.dtype)
         self_mask = torch.eye(S).log()                                               # attention_masks.py:110-113
         for i in range(tc.num_layers):
             p = f"denoiser.layers.{i}"

@@ -155,17 +155,18 @@ def test_qk_layernorm(ctx_norm, den_norm, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_denoiser_learned_positions(dtype):
-    """`pos_embedding_style="learned"` on the denoiser (lcm/nn/denoisers/factory.py:143, lcm_denoiser.py:211-212): in
-    the sampling loop the single latent sits at position 0 of the table; in the all-positions forward position j gets
-    row j.  Both against the oracle."""
+@pytest.mark.parametrize("style", ["learned", "sine"])
+def test_denoiser_learned_positions(dtype, style):
+    """`pos_embedding_style` "learned" / "sine" on the denoiser (lcm/nn/denoisers/factory.py:143, lcm_denoiser.py:211-212):
+    in the sampling loop the single latent sits at position 0 of the table; in the all-positions forward position j gets
+    row j.  Both against the oracle.  (The sinusoidal table is a buffer, not a state-dict entry.)"""
     from lcm.datasets.batch import EmbeddingsBatch
     from lcm.models.two_tower_diffusion_lcm import create_two_tower_diffusion_lcm_model
     from oracle.weights import synthetic_noise, synthetic_prompts
     cfg = O.get_arch(ARCH)
-    cfg.denoiser.pos = "learned"
+    cfg.denoiser.pos = style
     sd = O.init_state_dict(cfg, seed=8, mod_gain=4.0, qk_gain=1.5)
-    assert sd["denoiser.pos_encoder.weight"].shape == (cfg.max_seq_len, cfg.model_dim)
+    assert ("denoiser.pos_encoder.weight" in sd) == (style == "learned")
     norm = {"center": sd["sonar_normalizer.center"], "scale": sd["sonar_normalizer.scale"]}
     x, nz = synthetic_prompts(norm, 3, 4, seed=29), synthetic_noise(6, 3, seed=30)
     opts = dict(DEFAULT_OPTS, inference_timesteps=10)
@@ -174,7 +175,7 @@ def test_denoiser_learned_positions(dtype):
         x = O.r16(x)
     ref = run_oracle(cfg, sd, x, nz, 2, opts)
     mc = mini_config()
-    mc.denoiser.pos_embedding_style = "learned"
+    mc.denoiser.pos_embedding_style = style
     model = create_two_tower_diffusion_lcm_model(mc, device="cuda:0", dtype=dtype)
     assert set(model.state_dict()) == set(sd)
     model.load_state_dict(sd)
@@ -182,9 +183,11 @@ def test_denoiser_learned_positions(dtype):
     worst, cos = compare(out.hypotheses, ref, sd, start=4)
     if dtype == torch.float32:
         assert worst <= FP32_MAX_ABS and cos >= FP32_COS, (worst, cos)
-        without = dict(sd)
-        without["denoiser.pos_encoder.weight"] = torch.zeros_like(sd["denoiser.pos_encoder.weight"])
-        w_plain, _ = compare(out.hypotheses, run_oracle(cfg, without, x, nz, 2, opts), sd, start=4)
+        without, cfg0 = dict(sd), O.get_arch(ARCH)
+        if style == "learned":
+            cfg0 = cfg
+            without["denoiser.pos_encoder.weight"] = torch.zeros_like(sd["denoiser.pos_encoder.weight"])
+        w_plain, _ = compare(out.hypotheses, run_oracle(cfg0, without, x, nz, 2, opts), sd, start=4)
         assert w_plain > 10 * FP32_MAX_ABS, w_plain          # the table matters on this problem
     else:
         assert cos >= BF16_COS, (worst, cos)
@@ -464,7 +467,7 @@ def test_denoiser_options_the_reference_ignores_or_refuses():
     with pytest.raises(NotImplementedError):
         create_two_tower_diffusion_lcm_model(mc, device="cuda:0", dtype=torch.float32)
     mc = mini_config()
-    mc.denoiser.pos_embedding_style = "sine"
+    mc.denoiser.pos_embedding_style = "rope"
     with pytest.raises(NotImplementedError):
         create_two_tower_diffusion_lcm_model(mc, device="cuda:0", dtype=torch.float32)
     mc = mini_config()
