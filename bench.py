@@ -51,9 +51,6 @@ def parse():
     ap.add_argument("--no-check", action="store_true", help="skip the cross-check of the timed output")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch the sampling loop kernel by kernel instead of replaying it from a HIP graph (profiler counter passes)")
-    ap.add_argument("--separate-norms", action="store_true",
-                    help="A/B: every norm of a denoiser layer as its own kernel behind split-K products (9 launches per layer) "
-                         "instead of folded into the unsplit products around it (7)")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="ranks only rendezvous over gloo on the CPU and report the world size (no GPU work)")
     return ap.parse_args()
@@ -383,11 +380,9 @@ def main():
     model.init_parameters(seed=0, modulator_std=0.2)       # non-zero adaLN modulators: every layer does real work
     normalizer = load_model_from_card("dummy_sonar_normalizer", device=device, dtype=torch.bfloat16)
     model.sonar_normalizer.load_state_dict(normalizer.state_dict())
-    from lcm import _hip
     if args.no_graph:
-        model.session_flags |= _hip.SESSION_NO_GRAPH
-    if args.separate_norms:
-        model.session_flags |= _hip.SESSION_SEPARATE_NORMS
+        from lcm import _hip
+        model.session_flags = _hip.SESSION_NO_GRAPH
     gen = TwoTowerDiffusionLCMGenerator(model, DiffusionLCMGeneratorOptions(**opts))
 
     first_doc = rank * B

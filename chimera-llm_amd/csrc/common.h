@@ -256,28 +256,6 @@ __device__ __forceinline__ float act_slope(const GemmArgs& p) {
 bool gemm_stack_is_fused(const GemmArgs& a);
 // C = A W^T with the epilogue applied (split-K + finishing pass when a.partial is given and it pays).
 int launch_gemm(const GemmArgs& a, hipStream_t st);
-// Unsplit bf16 product on 32 x 32 tiles with the RMS norm of its operand on the load side and the residual update + the
-// next norm's row statistics on the store side (gemm_rows32.hip).
-struct Rows32Args {
-    const void* A;            // (M, K) bf16 operand rows, or null when x32 is given
-    const float* x32;         // (M, K) fp32 rows, normalized and modulated on load: ((x * rstd) * norm_w) * (1 + scale) + shift
-    const float* stats_in;    // [row][stats_parts] partial sums of squares of x32's rows (rstd = rsqrt(sum / K + eps))
-    int stats_parts;
-    const void* norm_w;       // (K,) bf16
-    const float* shift;       // (K,) fp32 or null (with scale)
-    const float* scale;
-    float eps;
-    const void* W;            // (N, K) bf16
-    const void* bias;         // (N,) bf16 or null; applied with resid only
-    const float* gate;        // (N,) fp32 or null
-    float* resid; int ldr;    // (M, N) fp32: resid = resid_in + gate * (acc + bias)   -- or --
-    const float* resid_in;    // null: resid itself (in place; not when x32 is the same buffer)
-    float* out32;             // (M, N) fp32: the raw product (no bias), as a split-K slab of one split
-    float* stats_out;         // [row][N / 16] partial sums of squares of the updated resid rows, or null
-    int M, N, K;
-};
-bool gemm_rows32_applicable(const Rows32Args& a);
-int launch_gemm_rows32(const Rows32Args& a, hipStream_t st);
 // Resolves the current device's copy of the static scratch array of lcmhip_gemm_static (noalloc.hip), once per device.
 int static_scratch_init();
 // Raw partial products only: slab [*splits][M][N] in a.partial, to be summed by the consumer.

@@ -222,8 +222,6 @@ struct lcmhip_session {
     bool stack_products = true;     // q / k / v (and cross k / v) of many rows in one launch; off with LCMHIP_SESSION_SEPARATE_QKV
     bool fuse_rope_store = true;    // ... with the rotation and the cache scatter in its epilogue; off with LCMHIP_SESSION_SEPARATE_ROPE
     bool use_graphs = true;         // the sampling loop is replayed from a HIP graph; off with LCMHIP_SESSION_NO_GRAPH
-    bool fuse_norms = true;         // denoiser norms folded into the products around them; off with LCMHIP_SESSION_SEPARATE_NORMS
-    float *stats0 = nullptr, *stats1 = nullptr;   // [row][model_dim / 16] partial sums of squares between fused products
     // carved device buffers
     int32_t *slot_map = nullptr, *pos_rows = nullptr, *self_rows = nullptr, *cross_rows = nullptr, *slot0_rows = nullptr;
     char *self_k = nullptr, *self_v = nullptr, *cross_k = nullptr, *cross_v = nullptr;
@@ -311,8 +309,6 @@ static size_t carve(lcmhip_session* s, char* base) {
     s->init_bias_pos = c.take<char>(dm * es);
     s->noise_buf = c.take<float>(B * D * 4);
     s->out_buf = c.take<float>(B * D * 4);
-    s->stats0 = c.take<float>(2 * B * (dm / 16) * 4);
-    s->stats1 = c.take<float>(2 * B * (dm / 16) * 4);
     return c.off;
 }
 
@@ -583,13 +579,6 @@ static int gemm_pending(lcmhip_session* s, const char* tag, const void* A, int l
     return LCMHIP_OK;
 }
 
-// Unsplit 32 x 32-tile product with the norms around it folded in (gemm_rows32.hip).
-static int rows32(lcmhip_session* s, const char* tag, const Rows32Args& a, hipStream_t st) {
-    const double wb = (double)a.N * a.K * 2.0, ab = (double)a.M * a.K * (a.x32 ? 4.0 : 2.0);
-    ProfScope ps(&s->prof, tag, wb + ab + (double)a.M * a.N * (a.resid ? 8.0 : 4.0), 2.0 * a.M * (double)a.N * a.K, st);
-    return launch_gemm_rows32(a, st);
-}
-
 static int norm(lcmhip_session* s, const char* tag, float* x, const NormW& w, const float* shift,
                 const float* scale, void* y, int rows_total, int rows_norm, int kind, const Pending* pend,
                 hipStream_t st, const RowSteps* steps = nullptr) {
@@ -773,7 +762,7 @@ int lcmhip_model_destroy(lcmhip_model* m) {
 // ------------------------------------------------------------------------------------------------ session life cycle
 static int session_dims(lcmhip_session* s, const lcmhip_model* m, int max_batch, int max_ctx, int max_steps, uint32_t flags) {
     constexpr uint32_t known = LCMHIP_SESSION_KEEP_CONTEXT | LCMHIP_SESSION_SEPARATE_QKV | LCMHIP_SESSION_SEPARATE_ROPE |
-                               LCMHIP_SESSION_NO_GRAPH | LCMHIP_SESSION_SEPARATE_NORMS;
+                               LCMHIP_SESSION_NO_GRAPH;
     LCM_REQUIRE((flags & ~known) == 0, "session: unknown flag bits");
     LCM_REQUIRE(m && m->finalized, "session: model is not finalized");
     LCM_REQUIRE(max_batch >= 1 && max_batch <= 65536, "session: max_batch");
@@ -791,7 +780,6 @@ static int session_dims(lcmhip_session* s, const lcmhip_model* m, int max_batch,
     s->stack_products = (flags & LCMHIP_SESSION_SEPARATE_QKV) == 0;
     s->fuse_rope_store = (flags & LCMHIP_SESSION_SEPARATE_ROPE) == 0;
     s->use_graphs = (flags & LCMHIP_SESSION_NO_GRAPH) == 0;
-    s->fuse_norms = (flags & LCMHIP_SESSION_SEPARATE_NORMS) == 0;
     return LCMHIP_OK;
 }
 
@@ -1212,60 +1200,7 @@ static int denoise_body(lcmhip_session* s, const float* noise, float* out, float
         pend.dup = 1;
         // one latent per call and no state bag: it sits at position 0 of the learned positions (bias + row 0, see set_schedule)
         if (m->den_pos_table) pend.bias = s->init_bias_pos;
-        // Fused form of a layer (bf16, RMSNorm, folded self-attention): the norms before the self-attention block and
-        // before the cross-attention query are folded into unsplit products (rows32) -- the product normalizes the fp32
-        // stream on load from the row statistics its predecessor left, and updates the stream in its own epilogue -- so
-        // a layer is 7 dependent launches instead of 9.  A product that reads the stream as its operand writes the
-        // updated rows into the other of two stream buffers (its tiles still read whole rows of the first).
-        bool fused = s->fuse_norms && d.dtype == LCMHIP_BF16 && td.norm_kind == LCMHIP_NORM_RMS && !td.qk_layernorm &&
-                     dm % 128 == 0 && dm <= 4096 && td.ffn_dim % 128 == 0;
-        for (int l = 0; l < L && fused; ++l) fused = m->den[l].ov.w != nullptr;
-        float* xcur = s->xres;
-        float* xalt = s->f32tmp;
-        for (int l = 0; l < L && fused; ++l) {
-            const DenLayer& Ly = m->den[l];
-            const float* mod = mod_step + (size_t)l * 9 * dm;
-            Rows32Args ov{};
-            ov.W = Ly.ov.w; ov.bias = Ly.ov.b; ov.gate = mod + 2 * dm; ov.ldr = dm; ov.stats_out = s->stats1;
-            ov.M = rows; ov.N = dm; ov.K = dm; ov.eps = d.norm_eps;
-            if (l == 0) {
-                // the initial projection's slabs start the stream (both halves of the doubled batch): the norm kernel
-                LCM_TRY(norm(s, "den.norm_mod", xcur, Ly.sa_norm, mod, mod + dm, s->act_a, rows, rows, td.norm_kind, &pend, st));
-                ov.A = s->act_a; ov.resid = xcur;
-            } else {
-                ov.x32 = xcur; ov.stats_in = s->stats0; ov.stats_parts = dm / 16;
-                ov.norm_w = Ly.sa_norm.w; ov.shift = mod; ov.scale = mod + dm;
-                ov.resid = xalt; ov.resid_in = xcur;
-            }
-            LCM_TRY(rows32(s, "den.self_ov", ov, st));
-            if (l != 0) std::swap(xcur, xalt);
-            // cross-attention query of the conditional rows, normalized on load; it stays fp32 for the attention kernel
-            Rows32Args q{};
-            q.x32 = xcur; q.stats_in = s->stats1; q.stats_parts = dm / 16;
-            q.norm_w = Ly.ca_norm.w; q.shift = mod + 3 * dm; q.scale = mod + 4 * dm; q.eps = d.norm_eps;
-            q.W = Ly.ca.q.w; q.out32 = s->slab_q; q.M = B; q.N = dm; q.K = dm;
-            LCM_TRY(rows32(s, "den.cross_q", q, st));
-            {
-                AttnQ qa{};
-                qa.partial = s->slab_q; qa.splits = 1; qa.rows = B; qa.bias = Ly.ca.q.b;
-                ProfScope ps(&s->prof, "den.cross_attn", 2.0 * B * (double)nkeys * dm * es + B * dm * (es + 4.0),
-                             4.0 * B * (double)nkeys * dm, st);
-                LCM_TRY(launch_attention_q(qa, s->cross_k + l * cross_layer, s->cross_v + l * cross_layer, s->slot_map,
-                                           s->act_o, B, 1, td.num_heads, s->cap + 1, nkeys, 0, d.dtype, st, keys_dev));
-            }
-            LCM_TRY(gemm_pending(s, "den.cross_o", s->act_o, dm, Ly.ca.o, mod + 5 * dm, B, &pend, st));
-            pend.extra_const = s->uconst + (size_t)l * dm;
-            LCM_TRY(norm(s, "den.norm_mod", xcur, Ly.ffn_norm, mod + 6 * dm, mod + 7 * dm, s->act_a, rows, rows, td.norm_kind, &pend, st));
-            LCM_TRY(ffn_in(s, "den.ffn_in", td, Ly.ffn, s->act_a, rows, st));
-            Rows32Args f2{};
-            f2.A = s->act_h; f2.W = Ly.ffn.out.w; f2.bias = Ly.ffn.out.b; f2.gate = mod + 8 * dm;
-            f2.resid = xcur; f2.ldr = dm; f2.stats_out = s->stats0; f2.M = rows; f2.N = dm; f2.K = td.ffn_dim;
-            LCM_TRY(rows32(s, "den.ffn_out", f2, st));
-        }
-        if (fused) {
-            LCM_TRY(norm(s, "den.norm_mod", xcur, m->den_final, nullptr, nullptr, s->act_a, rows, rows, td.norm_kind, nullptr, st));
-        }
-        for (int l = 0; l < L && !fused; ++l) {
+        for (int l = 0; l < L; ++l) {
             const DenLayer& Ly = m->den[l];
             const float* mod = mod_step + (size_t)l * 9 * dm;
             // self-attention over a single position: softmax == 1, so the block is output_proj(v_proj(h))
@@ -1302,7 +1237,7 @@ static int denoise_body(lcmhip_session* s, const float* noise, float* out, float
             LCM_TRY(ffn_in(s, "den.ffn_in", td, Ly.ffn, s->act_a, rows, st));
             LCM_TRY(gemm_pending(s, "den.ffn_out", s->act_h, td.ffn_dim, Ly.ffn.out, mod + 8 * dm, rows, &pend, st));
         }
-        if (!fused) LCM_TRY(norm(s, "den.norm_mod", s->xres, m->den_final, nullptr, nullptr, s->act_a, rows, rows, td.norm_kind, &pend, st));
+        LCM_TRY(norm(s, "den.norm_mod", s->xres, m->den_final, nullptr, nullptr, s->act_a, rows, rows, td.norm_kind, &pend, st));
         // the final projection stays in its split-K slab: the fused DDIM / guidance step sums it
         Pending fp;
         LCM_TRY(gemm_pending(s, "den.final_proj", s->act_a, dm, m->final_proj, nullptr, rows, &fp, st, s->slab_q));
@@ -1531,17 +1466,6 @@ int lcmhip_denormalize(const void* x, const void* center, const void* scale, con
                        void* y, int64_t rows, int32_t dim, int32_t dtype, void* stream) {
     LCM_REQUIRE(x && center && scale && y, "denormalize: null argument");
     return launch_normalize(x, center, scale, clip_min, clip_max, y, rows, dim, dtype, true, static_cast<hipStream_t>(stream));
-}
-
-int lcmhip_gemm_fused(const lcmhip_fused_product* f, void* stream) {
-    LCM_REQUIRE(f != nullptr && f->w != nullptr, "gemm_fused: null argument");
-    Rows32Args a{};
-    a.A = f->a; a.x32 = f->x32; a.stats_in = f->stats_in; a.stats_parts = f->stats_parts;
-    a.norm_w = f->norm_weight; a.shift = f->shift; a.scale = f->scale; a.eps = f->eps;
-    a.W = f->w; a.bias = f->bias; a.gate = f->gate;
-    a.resid = f->resid; a.resid_in = f->resid_in; a.ldr = f->ldr; a.out32 = f->out32; a.stats_out = f->stats_out;
-    a.M = f->M; a.N = f->N; a.K = f->K;
-    return launch_gemm_rows32(a, static_cast<hipStream_t>(stream));
 }
 
 int lcmhip_rfft_pack(const float* x, float* y, int64_t rows, int32_t dim, int32_t inverse, void* stream) {

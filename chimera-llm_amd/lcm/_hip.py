@@ -27,7 +27,7 @@ EPI_STORE, EPI_STORE_F32, EPI_RELU, EPI_SWIGLU, EPI_RESID = 0, 1, 2, 3, 4
 STATIC_SCRATCH_BYTES = 16 << 20      # LCMHIP_STATIC_SCRATCH_BYTES of include/lcmhip.h
 ABI_VERSION = 400                    # LCMHIP_ABI_VERSION of include/lcmhip.h: the layouts and signatures bound below
 # LCMHIP_SESSION_* flags of lcmhip_session_workspace_bytes / lcmhip_session_create
-SESSION_KEEP_CONTEXT, SESSION_SEPARATE_QKV, SESSION_SEPARATE_ROPE, SESSION_NO_GRAPH, SESSION_SEPARATE_NORMS = 1, 2, 4, 8, 16
+SESSION_KEEP_CONTEXT, SESSION_SEPARATE_QKV, SESSION_SEPARATE_ROPE, SESSION_NO_GRAPH = 1, 2, 4, 8
 
 EXPORTS = [
     "lcmhip_last_error", "lcmhip_version",
@@ -37,7 +37,7 @@ EXPORTS = [
     "lcmhip_denoise_positions",
     "lcmhip_session_reorder", "lcmhip_session_context_len", "lcmhip_session_num_active",
     "lcmhip_session_read_context", "lcmhip_session_profile_enable", "lcmhip_session_profile",
-    "lcmhip_normalize", "lcmhip_denormalize", "lcmhip_rfft_pack", "lcmhip_gemm_fused", "lcmhip_norm_modulate", "lcmhip_gemm", "lcmhip_static_init", "lcmhip_gemm_static", "lcmhip_gemm_partial",
+    "lcmhip_normalize", "lcmhip_denormalize", "lcmhip_rfft_pack", "lcmhip_norm_modulate", "lcmhip_gemm", "lcmhip_static_init", "lcmhip_gemm_static", "lcmhip_gemm_partial",
     "lcmhip_residual_norm",
     "lcmhip_ddim_cfg_step", "lcmhip_attention", "lcmhip_finalize_step", "lcmhip_stream_copy",
 ]
@@ -63,14 +63,6 @@ class DenoiseParams(C.Structure):
                 ("epsilon_scaling", C.c_float), ("clip_noise", C.c_float), ("init_noise_sigma", C.c_float),
                 ("prediction_type", C.c_int32), ("clip_sample", C.c_int32), ("clip_sample_range", C.c_float),
                 ("thresholding", C.c_int32), ("dynamic_thresholding_ratio", C.c_float), ("sample_max_value", C.c_float)]
-
-
-class FusedProduct(C.Structure):
-    _fields_ = [("a", C.c_void_p), ("x32", C.c_void_p), ("stats_in", C.c_void_p), ("stats_parts", C.c_int32),
-                ("norm_weight", C.c_void_p), ("shift", C.c_void_p), ("scale", C.c_void_p), ("eps", C.c_float),
-                ("w", C.c_void_p), ("bias", C.c_void_p), ("gate", C.c_void_p), ("resid", C.c_void_p), ("resid_in", C.c_void_p),
-                ("ldr", C.c_int32),
-                ("out32", C.c_void_p), ("stats_out", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32)]
 
 
 class ProfileRow(C.Structure):
@@ -116,7 +108,6 @@ def _load() -> C.CDLL:
         "lcmhip_normalize": [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp],
         "lcmhip_denormalize": [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp],
         "lcmhip_rfft_pack": [vp, vp, i64, i32, i32, vp],
-        "lcmhip_gemm_fused": [C.POINTER(FusedProduct), vp],
         "lcmhip_norm_modulate": [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp],
         "lcmhip_gemm": [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, C.c_size_t, vp],
         "lcmhip_static_init": [],

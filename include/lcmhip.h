@@ -30,7 +30,7 @@ extern "C" {
 /* Version of this ABI (struct layouts and signatures).  lcmhip_version() returns the value the library was built
  * with; a caller built against another value must not bind.  300 -> 400: lcmhip_tower_desc.norm_order,
  * no_final_norm and scale_residual, LCMHIP_POS_SINE, LCMHIP_ACT_PRELU, lcmhip_model_desc.postnet_activation,
- * lcmhip_rfft_pack, lcmhip_gemm_fused; 200 -> 300: lcmhip_session_workspace_bytes and
+ * lcmhip_rfft_pack; 200 -> 300: lcmhip_session_workspace_bytes and
  * lcmhip_session_create take `flags`, lcmhip_static_init added, lcmhip_tower_desc.ffn_activation; 100 -> 200: lcmhip_tower_desc.qk_layernorm,
  * thresholding fields of lcmhip_denoise_params, variance_noise of lcmhip_ddim_cfg_step. */
 #define LCMHIP_ABI_VERSION 400
@@ -174,9 +174,6 @@ int lcmhip_model_destroy(lcmhip_model* m);
 #define LCMHIP_SESSION_SEPARATE_ROPE 4u /* rotation of q / k and the cache scatter as a pass of their own, not in the
                                            stacked product's epilogue (same roundings: same bits) */
 #define LCMHIP_SESSION_NO_GRAPH 8u      /* the sampling loop is launched kernel by kernel, never replayed from a HIP graph */
-#define LCMHIP_SESSION_SEPARATE_NORMS 16u /* every norm of a denoiser layer as a kernel of its own after a split-K product
-                                           (nine launches per layer) instead of folded into the unsplit products around
-                                           it (lcmhip_gemm_fused: seven); other summation orders, same roundings */
 
 int lcmhip_session_workspace_bytes(const lcmhip_model* m, int32_t max_batch, int32_t max_ctx,
                                    int32_t max_steps, uint32_t flags, size_t* bytes);
@@ -298,39 +295,6 @@ int lcmhip_denormalize(const void* x, const void* center, const void* scale, con
  * [64, 4096]; y may equal x.  Forward (inverse = 0): X = rfft(x) without scaling, packed as
  * [Re X_0 .. Re X_{dim/2}, Im X_1 .. Im X_{dim/2-1}]; inverse (1): irfft of that packing (Im X_0 = Im X_{dim/2} = 0). */
 int lcmhip_rfft_pack(const float* x, float* y, int64_t rows, int32_t dim, int32_t inverse, void* stream);
-
-/* One product of a denoiser layer (lcm/nn/denoisers/lcm_denoiser.py:431-546) with the norm kernel on either side of it
- * folded in -- bf16 models with RMSNorm; the sampling loop uses it for the self-attention block, the cross-attention
- * query and the FFN's down-projection.  Operand side: either `a` ((M, K) bf16 rows) or `x32` ((M, K) fp32 rows of the
- * residual stream), which is normalized and modulated on load,
- *   h = ((x * rstd) * norm_weight) * (1 + scale) + shift, rounded to bf16, rstd = rsqrt(sum_j stats_in[row][j] / K + eps),
- * with stats_in [row][stats_parts] the partial sums of squares a previous call left in its `stats_out` (stats_parts a
- * multiple of 8, K a multiple of 128 and at most 4096).  Result side: either resid (M, N) fp32, ldr floats per row:
- *   resid = resid_in + gate * (h W^T + bias)  (gate (N,) fp32 or NULL = 1, bias (N,) bf16 or NULL; resid_in NULL = resid,
- *                                              in place -- not allowed when x32 is that buffer: other tiles still read it)
- * and, if stats_out is given, stats_out[row][j] = the sum of squares of columns 16 j .. 16 j + 15 of the UPDATED row
- * (N / 16 values per row); or out32 (M, N) fp32 = h W^T without the bias.  N a multiple of 32; no K split, so every
- * output is summed in one fixed order. */
-typedef struct {
-    const void* a;
-    const float* x32;
-    const float* stats_in;
-    int32_t stats_parts;
-    const void* norm_weight;  /* (K,) bf16 */
-    const float* shift;       /* (K,) fp32, or NULL together with scale */
-    const float* scale;
-    float eps;
-    const void* w;            /* (N, K) bf16, like torch.nn.Linear.weight */
-    const void* bias;
-    const float* gate;
-    float* resid;
-    const float* resid_in;
-    int32_t ldr;
-    float* out32;
-    float* stats_out;
-    int32_t M, N, K;
-} lcmhip_fused_product;
-int lcmhip_gemm_fused(const lcmhip_fused_product* args, void* stream);
 
 /* Layer/RMS norm (lcm/nn/normalization.py:73-88) fused with the adaLN modulation
  * `h * (1 + scale) + shift` of lcm_denoiser.py:449-452.  x: (rows, dim) fp32; weight/bias:

@@ -580,101 +580,3 @@ def test_gemm_activation_epilogues(hip, dtype, act):
     rc = hip.lib.lcmhip_gemm(hip.ptr(A), K, hip.ptr(W), None, None, None, None, hip.ptr(out), N, M, N, K,
                              hip.EPI_STORE | (hip.ACT["gelu"] << 8), hip.dtype_code(dtype), None, 0, _st(hip))
     assert rc == -1
-
-
-def _fused(hip, *, a=None, x32=None, stats_in=None, norm_w=None, shift=None, scale=None, w, bias=None, gate=None,
-           resid=None, resid_in=None, out32=None, stats_out=None, M, N, K, eps=1e-5):
-    f = hip.FusedProduct(
-        a=hip.ptr(a).value if a is not None else None, x32=hip.ptr(x32).value if x32 is not None else None,
-        stats_in=hip.ptr(stats_in).value if stats_in is not None else None,
-        stats_parts=0 if stats_in is None else stats_in.shape[1],
-        norm_weight=hip.ptr(norm_w).value if norm_w is not None else None,
-        shift=hip.ptr(shift).value if shift is not None else None, scale=hip.ptr(scale).value if scale is not None else None,
-        eps=eps, w=hip.ptr(w).value, bias=hip.ptr(bias).value if bias is not None else None,
-        gate=hip.ptr(gate).value if gate is not None else None, resid=hip.ptr(resid).value if resid is not None else None,
-        resid_in=hip.ptr(resid_in).value if resid_in is not None else None,
-        ldr=0 if resid is None else resid.stride(0), out32=hip.ptr(out32).value if out32 is not None else None,
-        stats_out=hip.ptr(stats_out).value if stats_out is not None else None, M=M, N=N, K=K)
-    return hip.lib.lcmhip_gemm_fused(C.byref(f), _st(hip))
-
-
-@pytest.mark.parametrize("M", [6, 70, 128, 256])
-@pytest.mark.parametrize("d,F", [(256, 768), (2048, 5632), (4096, 1024)])
-def test_gemm_fused_chain(hip, M, d, F):
-    """lcmhip_gemm_fused: the three forms the sampling loop chains -- (1) bf16 operand, residual update + row statistics;
-    (2) the next product normalizes the updated residual rows on load from those statistics and updates them again;
-    (3) a product that normalizes on load and leaves its raw fp32 result (the cross-attention query) -- against
-    float64 statements of the same roundings (operand rounded to bf16 after norm + modulation)."""
-    g = torch.Generator().manual_seed(M * 31 + d)
-    dev = "cuda:0"
-    r = lambda *s, std=1.0: (torch.randn(*s, generator=g) * std)
-    h = r(M, F).bfloat16()                                  # e.g. the FFN's inner activations
-    W1, b1 = r(d, F, std=F ** -0.5).bfloat16(), r(d, std=0.1).bfloat16()
-    W2, b2 = r(d, d, std=d ** -0.5).bfloat16(), r(d, std=0.1).bfloat16()
-    W3 = r(d, d, std=d ** -0.5).bfloat16()
-    g1, g2 = r(d, std=0.5), r(d, std=0.5)
-    nw2, nw3 = (1 + r(d, std=0.2)).bfloat16(), (1 + r(d, std=0.2)).bfloat16()
-    sh2, sc2, sh3, sc3 = r(d, std=0.3), r(d, std=0.3), r(d, std=0.3), r(d, std=0.3)
-    x0 = r(M, d)
-    # float64 statement
-    x1 = x0.double() + g1.double() * (h.double() @ W1.double().T + b1.double())
-
-    def operand(x, nw, sc, sh):
-        rstd = torch.rsqrt(x.float().pow(2).double().mean(-1, keepdim=True) + 1e-5)
-        return (((x.double() * rstd) * nw.double()) * (1 + sc.double()) + sh.double()).float().bfloat16()
-
-    x1f = x1.float()                                        # the stream is held in fp32
-    a2 = operand(x1f, nw2, sc2, sh2)
-    x2 = x1f.double() + g2.double() * (a2.double() @ W2.double().T + b2.double())
-    x2f = x2.float()
-    a3 = operand(x2f, nw3, sc3, sh3)
-    q = a3.double() @ W3.double().T
-    # device
-    D = lambda t: t.to(dev).contiguous()
-    x = D(x0)
-    st1 = torch.full((M, d // 16), float("nan"), device=dev)
-    st2 = torch.full((M, d // 16), float("nan"), device=dev)
-    assert _fused(hip, a=D(h), w=D(W1), bias=D(b1), gate=D(g1), resid=x, stats_out=st1, M=M, N=d, K=F) == 0, hip.lib.lcmhip_last_error()
-    torch.cuda.synchronize()
-    assert (x.cpu().double() - x1).abs().max() <= 2e-5 * x1.abs().max()
-    want_st = x.cpu().double().pow(2).view(M, d // 16, 16).sum(-1)
-    assert (st1.cpu().double() - want_st).abs().max() <= 1e-5 * want_st.abs().max()
-    x_after1 = x
-    x = torch.full_like(x_after1, float("nan"))             # the updated rows go to another buffer: every tile reads whole rows
-    assert _fused(hip, x32=x_after1, stats_in=st1, norm_w=D(nw2), shift=D(sh2), scale=D(sc2), w=D(W2), bias=D(b2), gate=D(g2),
-                  resid=x, resid_in=x_after1, stats_out=st2, M=M, N=d, K=d) == 0, hip.lib.lcmhip_last_error()
-    torch.cuda.synchronize()
-    assert _fused(hip, x32=x, stats_in=st1, norm_w=D(nw2), w=D(W2), resid=x, M=M, N=d, K=d) != 0      # in place: refused
-    # against the statement evaluated on the device's own intermediate stream (bf16 ties of the operand aside)
-    a2d = operand(x_after1.cpu(), nw2, sc2, sh2)
-    x2d = x_after1.cpu().double() + g2.double() * (a2d.double() @ W2.double().T + b2.double())
-    assert (x.cpu().double() - x2d).abs().max() <= 2e-3 * x2d.abs().max()
-    assert torch.nn.functional.cosine_similarity(x.cpu().double(), x2, dim=-1).min() >= 0.99999
-    qd = torch.full((M, d), float("nan"), device=dev)
-    assert _fused(hip, x32=x, stats_in=st2, norm_w=D(nw3), shift=D(sh3), scale=D(sc3), w=D(W3), out32=qd, M=M, N=d, K=d) == 0, hip.lib.lcmhip_last_error()
-    torch.cuda.synchronize()
-    assert torch.isfinite(qd).all()
-    assert torch.nn.functional.cosine_similarity(qd.cpu().double(), q, dim=-1).min() >= 0.9999
-    a3d = operand(x.cpu(), nw3, sc3, sh3)
-    q3d = a3d.double() @ W3.double().T
-    assert (qd.cpu().double() - q3d).abs().max() <= 2e-3 * q3d.abs().max()
-    # nothing written past row M, and a second run gives the same bits (fixed summation order)
-    x_b = torch.full_like(x, float("nan"))
-    st_b = torch.empty_like(st2)
-    _fused(hip, x32=x_after1, stats_in=st1, norm_w=D(nw2), shift=D(sh2), scale=D(sc2), w=D(W2), bias=D(b2), gate=D(g2),
-           resid=x_b, resid_in=x_after1, stats_out=st_b, M=M, N=d, K=d)
-    torch.cuda.synchronize()
-    assert torch.equal(x_b, x) and torch.equal(st_b, st2)
-
-
-def test_gemm_fused_rejects_bad_shapes(hip):
-    dev = "cuda:0"
-    w = torch.zeros(64, 200, device=dev, dtype=torch.bfloat16)
-    a = torch.zeros(8, 200, device=dev, dtype=torch.bfloat16)
-    x = torch.zeros(8, 64, device=dev)
-    assert _fused(hip, a=a, w=w, resid=x, M=8, N=64, K=200) != 0           # K not a multiple of 128
-    w = torch.zeros(48, 256, device=dev, dtype=torch.bfloat16)
-    a = torch.zeros(8, 256, device=dev, dtype=torch.bfloat16)
-    assert _fused(hip, a=a, w=w, resid=torch.zeros(8, 48, device=dev), M=8, N=48, K=256) != 0    # N not a multiple of 32
-    w = torch.zeros(64, 256, device=dev, dtype=torch.bfloat16)
-    assert _fused(hip, a=a, w=w, M=8, N=64, K=256) != 0                    # no result
