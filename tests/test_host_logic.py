@@ -129,7 +129,7 @@ def test_base_lcm_registry_and_no_cpu_fallback():
 def test_norm_styles_and_clipping_normalizer_shape_the_parameter_table():
     """Without a GPU: the `unit` norm style has no parameters, `fp32` and `rms` a weight only, `standard` weight and
     bias (lcm/nn/normalization.py:36-88); a model that names a normalizer card of the `clipping` arch carries
-    clip_min / clip_max (lcm/models/sonar_normalizer/builder.py:111-117), FFT variants are refused."""
+    clip_min / clip_max (lcm/models/sonar_normalizer/builder.py:111-117), one of an FFT arch its with_fft flag."""
     from lcm.models.sonar_normalizer.builder import SonarNormalizerConfig
     from lcm.models.two_tower_diffusion_lcm.builder import normalizer_config_for, parameter_spec
     from lcm.utils.card_utils import register_card
@@ -205,3 +205,57 @@ def test_fold_weight_norm_matches_torch_parametrization():
     bad = {"m.parametrizations.weight.original0": torch.ones(4, 1)}
     with pytest.raises(RuntimeError):
         fold_weight_norm(bad)
+
+
+@pytest.mark.parametrize("order,final,scale,swiglu,act", [("post", None, True, True, "relu"), ("normformer", None, False, False, "prelu"),
+                                                          ("pre", "post", True, False, "gelu"), ("normformer", "post", True, True, "relu")])
+def test_layer_options_shape_the_parameter_table(order, final, scale, swiglu, act):
+    """Without a GPU: norm order, final norm, residual scale, PReLU slope and bias-free projections give the state-dict
+    names of the reference's modules (lcm/nn/transformer/factory.py:152-300, lcm/nn/projection.py:60-67), two-tower and
+    base; the tower descriptors carry the options; the denoiser's stay at their defaults."""
+    from lcm import _hip
+    from lcm.models.base_lcm.builder import parameter_spec as base_parameter_spec
+    from lcm.models.two_tower_diffusion_lcm.builder import final_norm_absent, parameter_spec, tower_desc
+    from parity_utils import base_config, mini_config
+    cfg = mini_config()
+    tc = cfg.context_encoder
+    tc.norm_order_style, tc.final_norm_order_style, tc.use_swiglu, tc.ffn_inner_activation_name = order, final, swiglu, act
+    tc.scale_residual = 0.5 if scale else None
+    cfg.frontend.pre_linear_bias = cfg.denoiser.pre_denoiser.linear_bias = False
+    cfg.denoiser.scale_residual, cfg.denoiser.final_norm_order_style = 0.25, "post"      # ignored there, as in the reference
+    ocfg = oracle.get_arch("mini_two_tower_diffusion_lcm")
+    oc = ocfg.context
+    oc.norm_order, oc.final_norm_order, oc.use_swiglu, oc.activation, oc.scale_residual = order, final, swiglu, act, scale
+    ocfg.frontend_bias = ocfg.initial_proj_bias = False
+    spec = parameter_spec(cfg)
+    assert {n for n, _, _ in spec} == {n for n, _, _ in state_dict_spec(ocfg)}
+    kinds = {n: k for n, _, k in spec}
+    if scale:
+        assert kinds["context_encoder.layers.0.residual_scale"] == "const:0.5"
+    if act == "prelu" and not swiglu:
+        assert kinds["context_encoder.layers.1.ffn.inner_activation.weight"] == "const:0.25"
+    assert ("context_encoder.layer_norm.weight" in kinds) == (not final_norm_absent(tc)) == ((final or order) != "post")
+    assert "denoiser.layer_norm.weight" in kinds and not any("denoiser" in n and "residual_scale" in n for n in kinds)
+    t = tower_desc(tc)
+    assert (t.norm_order, t.no_final_norm, t.scale_residual) == (_hip.ORDER[order], int((final or order) == "post"), int(scale))
+    td = tower_desc(cfg.denoiser, denoiser=True)
+    assert (td.norm_order, td.no_final_norm, td.scale_residual) == (0, 0, 0)
+    # base LCM: the same stack options on `lcm.*`
+    bc = base_config("mini_base_lcm")
+    bc.lcm.norm_order_style, bc.lcm.final_norm_order_style, bc.lcm.use_swiglu, bc.lcm.ffn_inner_activation_name = order, final, swiglu, act
+    bc.lcm.scale_residual = 0.5 if scale else None
+    ob = oracle.get_base_arch("mini_base_lcm")
+    ob.lcm.norm_order, ob.lcm.final_norm_order, ob.lcm.use_swiglu, ob.lcm.activation, ob.lcm.scale_residual = order, final, swiglu, act, scale
+    from oracle.weights import base_state_dict_spec
+    assert {n for n, _, _ in base_parameter_spec(bc)} == {n for n, _, _ in base_state_dict_spec(ob)}
+
+
+def test_sinusoidal_table_equals_the_oracle_statement():
+    """The table handed to the library for sinusoidal positions on the denoiser's latents is the oracle's statement of
+    fairseq2's encoder (first half sines, second half cosines, frequencies exp(-i ln 10000 / (d / 2 - 1)))."""
+    from lcm.models.two_tower_diffusion_lcm.builder import sinusoidal_table
+    from oracle.model import sinusoidal_positions
+    got = sinusoidal_table(40, 256, device="cpu", dtype=torch.float32)
+    assert torch.equal(got, sinusoidal_positions(0, 40, 256))
+    assert torch.all(got[0, :128] == 0) and torch.all(got[0, 128:] == 1)
+    assert sinusoidal_table(8, 256, device="cpu", dtype=torch.bfloat16).dtype == torch.bfloat16
