@@ -766,9 +766,18 @@ __global__ __launch_bounds__(256) void k_ddim_step(const float* __restrict__ sam
     auto model_out = [&](const float* fin, int r, int ch) {
         if (io.partial == nullptr) return *reinterpret_cast<const float4*>(fin + base + ch * 4);
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int sp = 0; sp < io.splits; ++sp) {
-            const float4 t = *reinterpret_cast<const float4*>(io.partial + ((size_t)sp * io.rows_total + r) * dim + ch * 4);
-            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        // eight slabs requested at once (a loop of dependent load-add steps costs a memory round trip per slab); slabs
+        // past the split count repeat the last one and weigh 0; same summation order
+        for (int sp0 = 0; sp0 < io.splits; sp0 += 8) {
+            float4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                t[u] = *reinterpret_cast<const float4*>(io.partial + ((size_t)min(sp0 + u, io.splits - 1) * io.rows_total + r) * dim + ch * 4);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float on = sp0 + u < io.splits ? 1.f : 0.f;
+                a.x = fmaf(t[u].x, on, a.x); a.y = fmaf(t[u].y, on, a.y); a.z = fmaf(t[u].z, on, a.z); a.w = fmaf(t[u].w, on, a.w);
+            }
         }
         if (io.bias != nullptr) {
             if (io.bf16) {
