@@ -254,6 +254,9 @@ __device__ __forceinline__ float act_slope(const GemmArgs& p) {
 // True when launch_gemm would run this stacked product as ONE launch of a many-row kernel (whose epilogue knows the
 // per-matrix switches above); otherwise it runs one product per matrix and the switches must not be set.
 bool gemm_stack_is_fused(const GemmArgs& a);
+// Many-row kernels: does launch_gemm take them for this (unsplit) product, and what does the launch cost in waves of tiles?
+bool gemm_big_applicable(const GemmArgs& a, bool may_split);
+double gemm_big_wave_cost(const GemmArgs& a, int epi, int m_rows);
 // C = A W^T with the epilogue applied (split-K + finishing pass when a.partial is given and it pays).
 int launch_gemm(const GemmArgs& a, hipStream_t st);
 // Resolves the current device's copy of the static scratch array of lcmhip_gemm_static (noalloc.hip), once per device.

@@ -856,6 +856,15 @@ static int launch_gemm_big256(const GemmArgs& a_in, int epi, int m_rows, int wt,
     return LCMHIP_OK;
 }
 
+// Time of an unsplit many-row launch in units of one full wave of 128 x 128 tiles (512 workgroups), from the wave
+// quantisation and the measured wave-time ratio of the routing above.  For callers that can cut one product into two
+// launches (the stacked q / k / v product: q on its own + k, v stacked).
+double gemm_big_wave_cost(const GemmArgs& a, int epi, int m_rows) {
+    const int wrows = (epi == LCMHIP_EPI_SWIGLU ? 2 * a.N : a.N) * std::max(1, a.stack);
+    if (big256_applicable(a, epi, 1, m_rows)) return 1.6 * (((wrows / 256) * ((m_rows + 255) / 256) + 255) / 256);
+    return (double)(((wrows / kBN) * ((m_rows + kBM - 1) / kBM) + 511) / 512);
+}
+
 int launch_gemm_big(const GemmArgs& a, int epi, int splits, int m_rows, hipStream_t st) {
     if (a.stack > 1)
         LCM_REQUIRE(a.stack <= 3 && splits == 1 && a.N % kBN == 0 && (epi == LCMHIP_EPI_STORE || epi == LCMHIP_EPI_STORE_F32 || epi == LCMHIP_EPI_RELU),

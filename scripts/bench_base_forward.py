@@ -51,6 +51,15 @@ if os.environ.get("BF_AB_N128"):
             dt, _ = measure(10)
             print(f"round {rnd} LCMHIP_BIG256_N128={mode}: {dt * 1e3:.2f} ms per forward", flush=True)
     os.environ["LCMHIP_BIG256_N128"] = os.environ.get("BF_N128_FINAL", "1")
+# BF_AB_ENVVAR=NAME: any switch the library reads at every launch, "0" against "1", alternating in one process
+if os.environ.get("BF_AB_ENVVAR"):
+    name = os.environ["BF_AB_ENVVAR"]
+    for rnd in range(3):
+        for mode in ("0", "1"):
+            os.environ[name] = mode
+            dt, _ = measure(10)
+            print(f"round {rnd} {name}={mode}: {dt * 1e3:.2f} ms per forward", flush=True)
+    os.environ.pop(name, None)
 dt, out = measure(int(os.environ.get("BF_STEPS", "10")))
 assert torch.isfinite(out).all()
 d, F, L, H = cfg.model_dim, cfg.lcm.allocated_ffn_dim(), cfg.lcm.num_layers, cfg.lcm.num_attn_heads
