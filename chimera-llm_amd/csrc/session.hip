@@ -810,6 +810,19 @@ int lcmhip_session_workspace_bytes(const lcmhip_model* m, int32_t max_batch, int
     return LCMHIP_OK;
 }
 
+// Host -> device copy of set-up tables, complete on return.  It goes through a non-blocking stream of its own and not
+// through the legacy stream: a copy on the legacy stream waits for every blocking stream of the process and is refused
+// with an error while another thread records a graph on one.
+static int upload_now(void* dst, const void* src, size_t bytes) {
+    hipStream_t st = nullptr;
+    LCM_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipStreamDestroy(st);
+    if (e != hipSuccess) return fail(LCMHIP_ERR_HIP, std::string("set-up table upload: ") + hipGetErrorString(e));
+    return LCMHIP_OK;
+}
+
 int lcmhip_session_create(lcmhip_model* m, int32_t max_batch, int32_t max_ctx, int32_t max_steps, uint32_t flags,
                           void* workspace, size_t bytes, lcmhip_session** out) {
     LCM_REQUIRE(out && workspace, "session_create: null argument");
@@ -823,7 +836,7 @@ int lcmhip_session_create(lcmhip_model* m, int32_t max_batch, int32_t max_ctx, i
         std::vector<float> one(m->desc.model_dim, 1.0f);
         std::vector<uint16_t> one16(m->desc.model_dim, (uint16_t)0x3f80);   // 1.0 in bf16
         const void* src = m->desc.dtype == LCMHIP_BF16 ? (const void*)one16.data() : (const void*)one.data();
-        LCM_HIP_CHECK(hipMemcpy(s->ones, src, (size_t)m->desc.model_dim * dtype_size(m->desc.dtype), hipMemcpyHostToDevice));
+        LCM_TRY(upload_now(s->ones, src, (size_t)m->desc.model_dim * dtype_size(m->desc.dtype)));
     }
     // RoPE angle table, computed the way fairseq2's RotaryEncoder does (fp32 frequencies and angles).
     if (m->desc.context.pos_kind == LCMHIP_POS_ROPE) {
@@ -836,8 +849,8 @@ int lcmhip_session_create(lcmhip_model* m, int32_t max_batch, int32_t max_ctx, i
                 sn[(size_t)p * 64 + i] = (float)sin((double)ang);
             }
         }
-        LCM_HIP_CHECK(hipMemcpy(s->rope_cos, c.data(), c.size() * 4, hipMemcpyHostToDevice));
-        LCM_HIP_CHECK(hipMemcpy(s->rope_sin, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
+        LCM_TRY(upload_now(s->rope_cos, c.data(), c.size() * 4));
+        LCM_TRY(upload_now(s->rope_sin, sn.data(), sn.size() * 4));
     }
     *out = s.release();
     return LCMHIP_OK;

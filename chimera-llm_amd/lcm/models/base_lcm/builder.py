@@ -9,6 +9,7 @@ device tensors named like the reference's state dict (`frontend.pre_linear.*`, `
 
 import ctypes as C
 import logging
+import threading
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
@@ -163,6 +164,7 @@ class BaseLCModel(AbstractLCModel):
         self._handle = C.c_void_p()
         self._bind()
         self._session_pool: List[DeviceSession] = []
+        self._session_lock = threading.Lock()      # generators on several host threads share one model
         self.session_flags = 0     # _hip.SESSION_* bits given to every session this model creates (tests, profiling)
 
     # ---- parameters ---------------------------------------------------------------------------------
@@ -225,15 +227,26 @@ class BaseLCModel(AbstractLCModel):
 
     # ---- sessions -----------------------------------------------------------------------------------
     def acquire_session(self, max_batch: int, max_ctx: int) -> DeviceSession:
-        for i, s in enumerate(self._session_pool):
-            if s.dims[0] >= max_batch and s.dims[1] >= max_ctx and s.flags == int(self.session_flags):
-                return self._session_pool.pop(i)
-        self._session_pool.clear()
-        return DeviceSession(self, max_batch, max_ctx, 1)
+        sess = None
+        with self._session_lock:
+            for i, s in enumerate(self._session_pool):
+                if s.dims[0] >= max_batch and s.dims[1] >= max_ctx and s.flags == int(self.session_flags):
+                    sess = self._session_pool.pop(i)
+                    break
+            else:
+                self._session_pool.clear()
+        if sess is None:
+            return DeviceSession(self, max_batch, max_ctx, 1)
+        sess.unpark()
+        return sess
 
     def release_session(self, sess: Optional[DeviceSession]) -> None:
-        if sess is not None and not self._session_pool:
-            self._session_pool.append(sess)
+        if sess is None:
+            return
+        sess.park()
+        with self._session_lock:
+            if not self._session_pool:
+                self._session_pool.append(sess)
 
     def _session_for(self, bag: LCMIncrementalStateBag, batch_size: int) -> DeviceSession:
         if bag.session is None:

@@ -9,6 +9,7 @@ like the reference's state dict; a `DeviceSession` owns the KV caches and scratc
 """
 
 import ctypes as C
+import threading
 import math
 import logging
 from dataclasses import dataclass, field
@@ -255,6 +256,10 @@ class DeviceSession:
         self.workspace = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=model.device)
         base = (self.workspace.data_ptr() + 255) // 256 * 256
         self._h = C.c_void_p()
+        self._parked = None
+        # lcmhip_session_create writes its tables into the workspace before it returns, outside stream order: the
+        # allocator may have handed out a block that work still pending on this stream uses until it has run
+        torch.cuda.current_stream(model.device).synchronize()
         _hip.check(_hip.lib.lcmhip_session_create(model._handle, max_batch, max_ctx, max_steps, self.flags, C.c_void_p(base),
                                                   nbytes.value, C.byref(self._h)))
         self.schedule_key = None
@@ -266,6 +271,22 @@ class DeviceSession:
 
     def _stream(self):
         return _hip.stream_ptr(self.model.device)
+
+    def park(self) -> None:
+        """Called when the session goes back to the model's pool: marks the point in the releasing stream behind
+        which its caches are idle."""
+        self._parked = torch.cuda.Event()
+        self._parked.record(torch.cuda.current_stream(self.model.device))
+
+    def unpark(self) -> None:
+        """Called when a pooled session is taken again, possibly by another host thread on another stream: that
+        stream waits for the work the session was released with, and the allocator learns that the workspace is
+        in use there."""
+        cur = torch.cuda.current_stream(self.model.device)
+        if self._parked is not None:
+            cur.wait_event(self._parked)
+            self._parked = None
+        self.workspace.record_stream(cur)
 
     def set_schedule(self, timesteps: Optional[List[int]] = None) -> None:
         """Sampling schedule of the model's scheduler, or (with `timesteps`) only the adaLN table of the given
@@ -485,6 +506,7 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
         self._bind()
         self._refresh_derived()
         self._session_pool: List[DeviceSession] = []
+        self._session_lock = threading.Lock()      # generators on several host threads share one model
         self.session_flags = 0     # _hip.SESSION_* bits given to every session this model creates (tests, profiling)
 
     # ---- parameters ---------------------------------------------------------------------------------
@@ -612,26 +634,35 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
                 c.clip_sample, c.clip_sample_range, c.thresholding, c.dynamic_thresholding_ratio, c.sample_max_value)
 
     def acquire_session(self, max_batch: int, max_ctx: int, timesteps: Optional[List[int]] = None) -> DeviceSession:
-        self._ensure_folded()
         if timesteps is None:
             assert hasattr(self, "clip_noise"), (
                 "The model is not properly set for decoding, make sure to call `model.prep_for_denoising()`")
             steps = len(self.noise_scheduler.timesteps)
         else:
             steps = len(timesteps)
-        for i, s in enumerate(self._session_pool):
-            if s.dims[0] >= max_batch and s.dims[1] >= max_ctx and s.dims[2] >= steps and s.flags == int(self.session_flags):
-                sess = self._session_pool.pop(i)
-                break
-        else:
-            self._session_pool.clear()   # one workspace at a time: they are large
+        with self._session_lock:
+            self._ensure_folded()
+            sess = None
+            for i, s in enumerate(self._session_pool):
+                if s.dims[0] >= max_batch and s.dims[1] >= max_ctx and s.dims[2] >= steps and s.flags == int(self.session_flags):
+                    sess = self._session_pool.pop(i)
+                    break
+            else:
+                self._session_pool.clear()   # one workspace at a time: they are large
+        if sess is None:
             sess = DeviceSession(self, max_batch, max_ctx, steps)
+        else:
+            sess.unpark()
         sess.set_schedule(timesteps)
         return sess
 
     def release_session(self, sess: Optional[DeviceSession]) -> None:
-        if sess is not None and not self._session_pool:
-            self._session_pool.append(sess)
+        if sess is None:
+            return
+        sess.park()
+        with self._session_lock:
+            if not self._session_pool:
+                self._session_pool.append(sess)
 
     def _session_for(self, bag: LCMIncrementalStateBag, batch_size: int) -> DeviceSession:
         if bag.session is None:

@@ -15,7 +15,12 @@
  *    is given); weights must outlive the model handle; workspaces are allocated by the caller.
  *  - `stream` is a hipStream_t passed as void*; every kernel is enqueued on it; no call
  *    synchronises the device unless its comment says so.
- *  - a session is not thread-safe; use one session per (process, device).
+ *  - a session is not thread-safe: one host thread at a time calls into a given session.  Different sessions of one
+ *    model may be driven by different host threads on different streams at the same time (the model is read-only
+ *    after lcmhip_model_finalize).  A session records its sampling loop into a HIP graph with a THREAD-LOCAL
+ *    stream capture the first time it sees a shape; while that happens no other thread of the process may
+ *    synchronise the whole device (hipDeviceSynchronize), which this runtime refuses during any capture and which
+ *    invalidates the recording.  Stream and event synchronisation, copies and allocations by other threads are fine.
  */
 #ifndef LCMHIP_H
 #define LCMHIP_H
@@ -181,7 +186,8 @@ int lcmhip_session_workspace_bytes(const lcmhip_model* m, int32_t max_batch, int
 /* `workspace` (device, 256-byte aligned, `bytes` long) holds the contextualizer KV cache
  * (lcm/nn/incremental_state.py:14-43), the per-layer cross-attention K/V of the context, the
  * adaLN modulation table and all activations.  Replaces the LCMIncrementalStateBag pair of
- * generator.py:172-181. */
+ * generator.py:172-181.  The call writes its constant tables into the workspace before it returns, through a
+ * stream of its own: no work still pending on any stream may touch the workspace when it is called. */
 int lcmhip_session_create(lcmhip_model* m, int32_t max_batch, int32_t max_ctx, int32_t max_steps,
                           uint32_t flags, void* workspace, size_t bytes, lcmhip_session** out);
 int lcmhip_session_destroy(lcmhip_session* s);

@@ -45,7 +45,7 @@ def run_hip(arch, sd, x, nz, G, opts, dtype=torch.float32, prompt_lens=None, eos
     if prompt_lens is not None:
         mask = PaddingMask(torch.tensor(prompt_lens, device="cuda:0"), x.shape[1])
     out = gen(EmbeddingsBatch(x.cuda().to(dtype), mask), max_gen_len=G, noise=nz.cuda())
-    torch.cuda.synchronize()
+    torch.cuda.current_stream().synchronize()     # not device-wide: other host threads may be recording a graph
     return out, model
 
 
@@ -132,7 +132,7 @@ def run_hip_base(arch, sd, x, nz, G, opts, dtype=torch.float32, prompt_lens=None
     if prompt_lens is not None:
         mask = PaddingMask(torch.tensor(prompt_lens, device="cuda:0"), x.shape[1])
     out = gen(EmbeddingsBatch(x.cuda().to(dtype), mask), max_gen_len=G, noise=nz.cuda(), disable_cache=disable_cache)
-    torch.cuda.synchronize()
+    torch.cuda.current_stream().synchronize()     # not device-wide: other host threads may be recording a graph
     return out, model
 
 
