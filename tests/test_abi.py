@@ -79,6 +79,13 @@ def test_model_table_validation_without_gpu(hip):
     den.pos_kind = 2
     desc.denoiser = den
     assert hip.lib.lcmhip_model_create(C.byref(desc), C.byref(handle)) == -3
+    # the kernels are written for heads of 128 columns: any other head width is refused by name
+    den.pos_kind = 0
+    desc.denoiser = den
+    tower.num_heads = 4                 # 256 / 4 = 64 columns per head
+    desc.context = tower
+    assert hip.lib.lcmhip_model_create(C.byref(desc), C.byref(handle)) == -1
+    assert b"head_dim must be 128" in hip.lib.lcmhip_last_error()
 
 
 def test_library_override_and_version_gate(tmp_path, hip):
