@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <memory>
 #include <string>
 #include <vector>
@@ -236,6 +237,8 @@ struct lcmhip_session {
     int32_t* d_cross_keys = nullptr;              // device copy of ctx_len + 1 (read by graph-recorded attention launches)
     float *noise_buf = nullptr, *out_buf = nullptr;   // fixed addresses for graph-recorded denoising
     std::map<int, hipGraphExec_t> graphs;         // one recorded denoising loop per number of active documents
+    hipStream_t graph_stream = nullptr;           // the stream the last recorded loop was launched on
+    bool graph_launched = false;
     size_t slab_bytes = 0;
     // host state
     std::vector<int32_t> h_slot;
@@ -813,12 +816,18 @@ int lcmhip_session_workspace_bytes(const lcmhip_model* m, int32_t max_batch, int
 // Host -> device copy of set-up tables, complete on return.  It goes through a non-blocking stream of its own and not
 // through the legacy stream: a copy on the legacy stream waits for every blocking stream of the process and is refused
 // with an error while another thread records a graph on one.
+// The stream is created once per device and kept: uploads are rare and serialised.
 static int upload_now(void* dst, const void* src, size_t bytes) {
-    hipStream_t st = nullptr;
-    LCM_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipStreamDestroy(st);
+    constexpr int kMaxDevices = 64;
+    static std::mutex mu;
+    static hipStream_t streams[kMaxDevices] = {};
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    LCM_HIP_CHECK(hipGetDevice(&dev));
+    LCM_REQUIRE(dev >= 0 && dev < kMaxDevices, "set-up table upload: device index out of range");
+    if (streams[dev] == nullptr) LCM_HIP_CHECK(hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking));
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, streams[dev]);
+    if (e == hipSuccess) e = hipStreamSynchronize(streams[dev]);
     if (e != hipSuccess) return fail(LCMHIP_ERR_HIP, std::string("set-up table upload: ") + hipGetErrorString(e));
     return LCMHIP_OK;
 }
@@ -856,7 +865,14 @@ int lcmhip_session_create(lcmhip_model* m, int32_t max_batch, int32_t max_ctx, i
     return LCMHIP_OK;
 }
 
+// A recorded loop may still be executing when its session is destroyed, re-scheduled or asked for a seventeenth batch
+// size: the executable graphs (which own the kernel arguments of their nodes) are destroyed only after the stream the
+// last one was launched on has drained.
 static void drop_graphs(lcmhip_session* s) {
+    if (s->graph_launched && !s->graphs.empty()) {
+        if (hipStreamSynchronize(s->graph_stream) != hipSuccess) (void)hipGetLastError();   // a stream the caller has destroyed since
+        s->graph_launched = false;
+    }
     for (auto& kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
     s->graphs.clear();
 }
@@ -1312,6 +1328,10 @@ static int denoise_impl(lcmhip_session* s, const float* noise, const float* vari
     auto it = s->graphs.find(s->n_active);
     if (it == s->graphs.end()) {
         if (s->graphs.size() >= 16) drop_graphs(s);   // documents finishing one by one: keep the cache bounded
+        // one recording at a time in the process: sessions on other host threads wait here (a recording is a few
+        // thousand captured launches, once per session and batch size), they do not record side by side
+        static std::mutex record_mutex;
+        std::lock_guard<std::mutex> recording(record_mutex);
         hipGraph_t graph = nullptr;
         LCM_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         const int rc = denoise_body(s, s->noise_buf, s->out_buf, nullptr, st, s->d_cross_keys);
@@ -1329,6 +1349,8 @@ static int denoise_impl(lcmhip_session* s, const float* noise, const float* vari
     }
     LCM_HIP_CHECK(hipMemcpyAsync(s->noise_buf, noise, io_bytes, hipMemcpyDeviceToDevice, st));
     LCM_HIP_CHECK(hipGraphLaunch(it->second, st));
+    s->graph_stream = st;
+    s->graph_launched = true;
     LCM_HIP_CHECK(hipMemcpyAsync(out, s->out_buf, io_bytes, hipMemcpyDeviceToDevice, st));
     return LCMHIP_OK;
 }
