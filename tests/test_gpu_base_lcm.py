@@ -318,3 +318,40 @@ def test_base_prelu_many_rows_bf16():
         out = model.predict_next_sentence(EmbeddingsBatch(xd.cuda().to(dtype), None)).seqs.float().cpu()
         cos = torch.nn.functional.cosine_similarity(out, ref, dim=-1).min()
         assert cos >= (FP32_COS if dtype == torch.float32 else BF16_COS), (dtype, cos)
+
+
+def test_option_statements_against_golden_fixture():
+    """The committed vectors of tests/golden/option_statements_golden.pt (written by oracle/make_golden_options.py)
+    through the HIP path, fp32: layer orders, the stack without a final norm, residual scale, sinusoidal positions, PReLU,
+    postnet activation and projections without biases on the base LCM; the packed real FFT on its own.  No oracle
+    arithmetic runs here beyond the seeded weight initialisation."""
+    import os
+
+    from lcm import _hip
+    from lcm.datasets.batch import EmbeddingsBatch
+    from lcm.models.base_lcm import create_base_lcm_model
+    from oracle import make_golden_options as G
+    blob = torch.load(os.path.join(os.path.dirname(__file__), "golden", "option_statements_golden.pt"), weights_only=True)
+    lcm_side = {
+        "post_sine": lambda mc: (setattr(mc.lcm, "norm_order_style", "post"), setattr(mc.lcm, "pos_embedding_style", "sine")),
+        "normformer_nofinal_rope_scaled": lambda mc: (setattr(mc.lcm, "norm_order_style", "normformer"),
+                                                      setattr(mc.lcm, "final_norm_order_style", "post"),
+                                                      setattr(mc.lcm, "scale_residual", 0.5)),
+        "relu_ffn_prelu": lambda mc: (setattr(mc.lcm, "use_swiglu", False), setattr(mc.lcm, "ffn_inner_activation_name", "prelu")),
+        "postnet_tanh_no_biases": lambda mc: (setattr(mc.postnet, "activation_name", "tanh"), setattr(mc.postnet, "linear_bias", False),
+                                              setattr(mc.frontend, "pre_linear_bias", False)),
+    }
+    for name, edit in lcm_side.items():
+        cfg, sd, x = G.base_case(name)
+        mc = base_config("mini_base_lcm")
+        edit(mc)
+        model = create_base_lcm_model(mc, device="cuda:0", dtype=torch.float32)
+        assert set(model.state_dict()) == set(sd), name
+        model.load_state_dict(sd)
+        case = blob["base"][name]
+        out = model.predict_next_sentence(EmbeddingsBatch(case["prompts"].cuda(), None)).seqs.cpu()
+        assert (out - case["predict"]).abs().max() <= 2e-4 * case["predict"].abs().max(), name
+        assert torch.nn.functional.cosine_similarity(out, case["predict"], dim=-1).min() >= FP32_COS, name
+    f = blob["fft"]
+    assert (_hip.rfft_pack(f["x"].cuda(), inverse=False).cpu() - f["packed"]).abs().max() <= 5e-6 * f["packed"].abs().max()
+    assert (_hip.rfft_pack(f["packed"].cuda(), inverse=True).cpu() - f["back"]).abs().max() <= 5e-6 * f["back"].abs().max()

@@ -212,6 +212,26 @@ def test_golden_fixture_regression():
     assert (trace[len(blob["timesteps"]) - 1][2] - blob["x0_last"]).abs().max() <= 1e-4
 
 
+def test_option_statements_fixture_regression():
+    """tests/golden/option_statements_golden.pt (oracle/make_golden_options.py): the oracle's statements of the layer
+    orders, residual scale, sinusoidal positions, PReLU, postnet activation and packed FFT still give the committed
+    vectors."""
+    from oracle import make_golden_options as G
+    from oracle.model import fft_inverse_transform, fft_transform, sinusoidal_positions
+    blob = torch.load(os.path.join(os.path.dirname(__file__), "golden", "option_statements_golden.pt"), weights_only=True)
+    assert set(blob["base"]) == set(G.BASE_CASES)
+    for name, case in blob["base"].items():
+        cfg, sd, x = G.base_case(name)
+        assert torch.equal(x, case["prompts"]), name
+        out = oracle.OracleBaseLCM(cfg, sd).predict(x)
+        assert (out - case["predict"]).abs().max() <= 1e-5 * case["predict"].abs().max(), name
+    f = blob["fft"]
+    assert (fft_transform(f["x"]) - f["packed"]).abs().max() <= 1e-5 * f["packed"].abs().max()
+    assert (fft_inverse_transform(f["packed"]) - f["back"]).abs().max() <= 1e-5
+    assert (f["back"] - f["x"]).abs().max() <= 1e-4
+    assert (sinusoidal_positions(3, 5, 256) - blob["sine_rows_3_to_7_dim_256"]).abs().max() <= 1e-6
+
+
 def test_dummy_normalizer_fixture():
     n = oracle.load_dummy_normalizer()
     assert n["center"].shape == (1024,) and n["scale"].shape == (1024,) and n["center"].dtype == torch.float32
