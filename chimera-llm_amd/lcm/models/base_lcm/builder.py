@@ -235,6 +235,7 @@ class BaseLCModel(AbstractLCModel):
                     break
             else:
                 self._session_pool.clear()
+            s = None                         # the loop variable would keep the dropped session's workspace alive below
         if sess is None:
             return DeviceSession(self, max_batch, max_ctx, 1)
         sess.unpark()

@@ -649,6 +649,7 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
                     break
             else:
                 self._session_pool.clear()   # one workspace at a time: they are large
+            s = None                         # the loop variable would keep the dropped session's workspace alive below
         if sess is None:
             sess = DeviceSession(self, max_batch, max_ctx, steps)
         else:

@@ -166,6 +166,25 @@ def test_document_shards_equal_one_batch(dtype):
     del model
 
 
+def test_session_pool_holds_one_workspace_at_a_time():
+    """A call that needs a larger session than the pooled one drops the pooled workspace BEFORE it allocates the new
+    one (at 2048 documents x 500 positions a workspace is 142 GB: two of them do not fit)."""
+    arch = "mini_two_tower_diffusion_lcm"
+    cfg, sd, x, nz = make_problem(arch, 6, 40, 8)
+    opts = dict(DEFAULT_OPTS, inference_timesteps=10)
+    _, model = run_hip(arch, sd, x, nz, 1, opts)
+    w1 = model._session_pool[0].workspace.numel()
+    torch.cuda.synchronize()
+    a0 = torch.cuda.memory_allocated()
+    torch.cuda.reset_peak_memory_stats()
+    run_hip(arch, sd, x, nz, 8, opts, model=model)            # more positions: the pooled session is too small
+    w2 = model._session_pool[0].workspace.numel()
+    assert w2 > w1 > (1 << 20)
+    peak = torch.cuda.max_memory_allocated()
+    assert peak < a0 + w2 - w1 // 2, (a0, w1, w2, peak)        # both alive at once would be >= a0 + w2
+    del model
+
+
 def test_no_cpu_fallback():
     from lcm.models.two_tower_diffusion_lcm import create_two_tower_diffusion_lcm_model, lcm_archs
     with pytest.raises(RuntimeError, match="no CPU fallback"):
