@@ -78,6 +78,36 @@ def test_mini_long_ragged_prompts(dtype):
         assert cos >= BF16_COS, (worst, cos)
 
 
+def test_mini_generation_at_the_context_limit():
+    """A session's longest context: 3800 positions.  Prompts of 3792 / 3700 sentences + 6 generated (prefill in several
+    passes of the many-row kernels, decode attention and cross-attention over ~3800 keys) against the oracle, fp32; one
+    position more is refused by name."""
+    from lcm.models.two_tower_diffusion_lcm import create_two_tower_diffusion_lcm_model
+    from oracle.weights import synthetic_noise, synthetic_prompts
+    from parity_utils import mini_config
+    lens, G = [3792, 3700], 6
+    cfg = oracle_mod.get_arch("mini_two_tower_diffusion_lcm")
+    cfg.max_seq_len = 4096
+    sd = oracle_mod.init_state_dict(cfg, seed=3, mod_gain=4.0, qk_gain=1.0)
+    x = synthetic_prompts({"center": sd["sonar_normalizer.center"], "scale": sd["sonar_normalizer.scale"]}, 2, max(lens), seed=1237)
+    x[1, lens[1]:] = 0
+    nz = synthetic_noise(G + max(lens), 2, seed=4324)
+    opts = dict(DEFAULT_OPTS, inference_timesteps=10)
+    ref = run_oracle(cfg, sd, x, nz, G, opts, prompt_lens=lens)
+    mc = mini_config()
+    mc.max_seq_len = 4096
+    model = create_two_tower_diffusion_lcm_model(mc, device="cuda:0", dtype=torch.float32)
+    model.load_state_dict(sd)
+    out, _ = run_hip("mini_two_tower_diffusion_lcm", sd, x, nz, G, opts, prompt_lens=lens, model=model)
+    assert [h[0].seq.shape[0] for h in out.hypotheses] == [n + G for n in lens]
+    for n, hh, hr in zip(lens, out.hypotheses, ref):
+        worst, cos = compare([hh], [hr], sd, start=n)
+        assert worst <= FP32_MAX_ABS and cos >= FP32_COS, (n, worst, cos)
+    with pytest.raises(RuntimeError, match="3800"):
+        run_hip("mini_two_tower_diffusion_lcm", sd, x, nz, G + 3, opts, prompt_lens=lens, model=model)
+    del model
+
+
 def test_ragged_prompts_and_early_finish():
     """Ragged prompts: rows still inside their prompt keep the prompt embedding, documents finish at
     different steps (prompt_len + max_gen_len) and leave the batch."""

@@ -383,6 +383,36 @@ def test_attention(hip, dtype, causal, s, base):
     assert (out.float().cpu() - ref).abs().max() <= tol
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("causal,s,base", [(0, 1, 3801), (1, 1, 3800), (1, 96, 3705), (1, 3801, 0)])
+def test_attention_at_the_context_limit(hip, dtype, causal, s, base):
+    """The longest cache a session may hold: 3800 context positions + the zero slot = 3801 keys per document.  One
+    query over all of them (the sampling loop's cross-attention at the limit), the last positions of a long prompt, and a
+    whole 3801-position prompt through the prefill kernel (bf16) / the one-query kernel (fp32)."""
+    from oracle.model import sdpa
+    torch.manual_seed(11)
+    n_docs, H, cap = 2, 4, 3801
+    d = H * 128
+    kc = torch.randn(3, H, cap, 128).cuda().to(dtype)
+    vc = torch.randn(3, H, cap, 128).cuda().to(dtype)
+    slot = torch.tensor([2, 0], dtype=torch.int32).cuda()
+    q = (2 * torch.randn(n_docs * s, d)).cuda().to(dtype)
+    out = torch.empty_like(q)
+    hip.check(hip.lib.lcmhip_attention(hip.ptr(q), hip.ptr(kc), hip.ptr(vc), hip.ptr(slot), hip.ptr(out), n_docs, s, H, cap,
+                                       base, causal, hip.dtype_code(dtype), _st(hip)))
+    nk = base + (s if causal else 0)
+    assert nk == cap
+    qh = q.float().cpu().view(n_docs, s, H, 128).transpose(1, 2)
+    kh = kc.float().cpu()[[2, 0]]
+    vh = vc.float().cpu()[[2, 0]]
+    mask = None
+    if causal and s > 1:
+        mask = torch.full((nk, nk), float("-inf")).triu(1)[nk - s:]
+    ref = sdpa(qh, kh, vh, None, mask).transpose(1, 2).reshape(n_docs * s, d)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert (out.float().cpu() - ref).abs().max() <= tol
+
+
 @pytest.mark.parametrize("n_docs,H,s,base", [(3, 4, 30, 0), (5, 4, 70, 3), (1, 12, 129, 64), (7, 16, 64, 63)])
 def test_attention_prefill_grid_shapes(hip, n_docs, H, s, base):
     """The matrix-core prefill kernel over grids that are and are not a multiple of the 8 XCDs (its tile order is
