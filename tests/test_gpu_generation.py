@@ -108,6 +108,19 @@ def test_mini_generation_at_the_context_limit():
     del model
 
 
+def test_toy_every_training_step_as_a_sampling_step():
+    """`inference_timesteps` = the scheduler's 1000 training steps: the longest schedule the toy arch can ask for (a
+    modulation table of 1000 x 2 layers, a recorded loop of ~22 000 kernel nodes), one sentence, against the oracle."""
+    arch = "toy_two_tower_diffusion_lcm"
+    cfg, sd, x, nz = make_problem(arch, 2, 3, 1)
+    opts = dict(DEFAULT_OPTS, inference_timesteps=1000)
+    ref = run_oracle(cfg, sd, x, nz, 1, opts)
+    out, model = run_hip(arch, sd, x, nz, 1, opts)
+    assert len(model.noise_scheduler.timesteps) == 1000
+    worst, cos = compare(out.hypotheses, ref, sd, start=3)
+    assert worst <= FP32_MAX_ABS and cos >= FP32_COS, (worst, cos)
+
+
 def test_ragged_prompts_and_early_finish():
     """Ragged prompts: rows still inside their prompt keep the prompt embedding, documents finish at
     different steps (prompt_len + max_gen_len) and leave the batch."""
