@@ -647,6 +647,8 @@ int lcmhip_model_create(const lcmhip_model_desc* desc, lcmhip_model** out) {
     LCM_REQUIRE(desc && out, "model_create: null argument");
     LCM_REQUIRE(desc->dtype == LCMHIP_F32 || desc->dtype == LCMHIP_BF16, "model_create: dtype must be f32 or bf16");
     LCM_REQUIRE(desc->sonar_dim % 128 == 0 && desc->sonar_dim <= 4096, "model_create: sonar_dim");
+    // the frontend and the initial projection stream their K = sonar_dim operands in whole 512-byte chunks
+    LCM_REQUIRE(desc->dtype != LCMHIP_BF16 || desc->sonar_dim % 256 == 0, "model_create: sonar_dim must be a multiple of 256 in bf16");
     LCM_REQUIRE(desc->model_dim % 256 == 0 && desc->model_dim <= 8192, "model_create: model_dim");
     LCM_REQUIRE(desc->timestep_freq_dim % 64 == 0 && desc->timestep_freq_dim > 0, "model_create: timestep_freq_dim");
     LCM_TRY(check_tower(desc->context, desc->model_dim, "context"));

@@ -573,3 +573,47 @@ def test_fft_normalizer(tmp_path, clip):
     assert (model.sonar_normalizer.normalize(x.cuda()).cpu() - want).abs().max() <= 1e-5 * max(1.0, float(want.abs().max()))
     back = n.denormalize(want.cuda()).cpu()
     assert (back - om.denormalize(want)).abs().max() <= 1e-5 * max(1.0, float(x.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("D", [768, 2048])
+def test_embedding_widths_other_than_1024(D, dtype):
+    """`sonar_embed_dim` other than SONAR's 1024 (abstract_lcm/builder.py:28): normalizer, frontend, initial / final
+    projection, the DDIM / guidance step and finalize_step over D columns, against the oracle; a width the bf16 operand
+    stream cannot take (not a multiple of 256) is refused when the model is built."""
+    import oracle.weights as W
+    from lcm.models.two_tower_diffusion_lcm import create_two_tower_diffusion_lcm_model
+    from oracle.weights import synthetic_noise, synthetic_prompts
+    from parity_utils import mini_config
+    cfg = O.get_arch("mini_two_tower_diffusion_lcm")
+    cfg.sonar_dim = D
+    dummy = O.load_dummy_normalizer()
+    norm = {k: dummy[k].repeat(4)[:D].clone() for k in ("center", "scale")}
+    orig, W.load_dummy_normalizer = W.load_dummy_normalizer, (lambda: norm)
+    try:
+        sd = O.init_state_dict(cfg, seed=2, mod_gain=10.0, qk_gain=2.0)
+    finally:
+        W.load_dummy_normalizer = orig
+    x = synthetic_prompts(norm, 3, 4, seed=77)
+    nz = synthetic_noise(3 + 4, 3, dim=D, seed=78)
+    if dtype == torch.bfloat16:
+        sd = {k: v.bfloat16().float() for k, v in sd.items()}
+        x = x.bfloat16().float()
+    opts = dict(DEFAULT_OPTS, inference_timesteps=10, eos_threshold=0.9)
+    eos = torch.randn(D)
+    ref = run_oracle(cfg, sd, x, nz, 3, opts, eos_vec=eos)
+    mc = mini_config()
+    mc.sonar_embed_dim = D
+    model = create_two_tower_diffusion_lcm_model(mc, device="cuda:0", dtype=dtype)
+    model.load_state_dict(sd)
+    out, _ = run_hip("mini_two_tower_diffusion_lcm", sd, x, nz, 3, opts, dtype=dtype, model=model, eos_vec=eos)
+    worst, cos = compare(out.hypotheses, ref, sd, start=4)
+    if dtype == torch.float32:
+        assert worst <= 1e-3 and cos >= 0.9999, (worst, cos)
+    else:
+        assert cos >= 0.999, (worst, cos)
+    del model
+    mc.sonar_embed_dim = 640
+    if dtype == torch.bfloat16:
+        with pytest.raises(RuntimeError, match="multiple of 256"):
+            create_two_tower_diffusion_lcm_model(mc, device="cuda:0", dtype=dtype)
