@@ -196,11 +196,13 @@ static int get_ffn(lcmhip_model* m, const std::string& p, int d, const lcmhip_to
     return LCMHIP_OK;
 }
 
-static int check_tower(const lcmhip_tower_desc& t, int d, const char* which) {
+static int check_tower(const lcmhip_tower_desc& t, int d, int dtype, const char* which) {
     LCM_REQUIRE(t.num_layers >= 1, std::string(which) + ": needs at least one layer");
     LCM_REQUIRE(t.num_heads >= 2 && d == t.num_heads * 128, std::string(which) + ": head_dim must be 128");
     LCM_REQUIRE(t.num_heads % 4 == 0 || t.num_heads == 2, std::string(which) + ": heads must be 2 or a multiple of 4");
-    LCM_REQUIRE(t.ffn_dim % 128 == 0, std::string(which) + ": ffn_dim must be a multiple of 128");
+    // the down-projection streams K = ffn_dim operands in whole 512-byte chunks
+    LCM_REQUIRE(t.ffn_dim % (dtype == LCMHIP_BF16 ? 256 : 128) == 0,
+                std::string(which) + ": ffn_dim must be a multiple of 128 (fp32) / 256 (bf16)");
     LCM_REQUIRE(t.norm_kind >= LCMHIP_NORM_LAYERNORM && t.norm_kind <= LCMHIP_NORM_UNIT, "unknown norm kind");
     LCM_REQUIRE(t.ffn_kind == LCMHIP_FFN_RELU || t.ffn_kind == LCMHIP_FFN_SWIGLU, "unknown ffn kind");
     LCM_REQUIRE(t.ffn_activation >= LCMHIP_ACT_RELU && t.ffn_activation <= LCMHIP_ACT_PRELU, "unknown ffn activation");
@@ -650,11 +652,12 @@ int lcmhip_model_create(const lcmhip_model_desc* desc, lcmhip_model** out) {
     // the frontend and the initial projection stream their K = sonar_dim operands in whole 512-byte chunks
     LCM_REQUIRE(desc->dtype != LCMHIP_BF16 || desc->sonar_dim % 256 == 0, "model_create: sonar_dim must be a multiple of 256 in bf16");
     LCM_REQUIRE(desc->model_dim % 256 == 0 && desc->model_dim <= 8192, "model_create: model_dim");
-    LCM_REQUIRE(desc->timestep_freq_dim % 64 == 0 && desc->timestep_freq_dim > 0, "model_create: timestep_freq_dim");
-    LCM_TRY(check_tower(desc->context, desc->model_dim, "context"));
+    LCM_REQUIRE(desc->timestep_freq_dim > 0 && desc->timestep_freq_dim % (desc->dtype == LCMHIP_BF16 ? 256 : 128) == 0,
+                "model_create: timestep_freq_dim must be a multiple of 128 (fp32) / 256 (bf16)");
+    LCM_TRY(check_tower(desc->context, desc->model_dim, desc->dtype, "context"));
     const bool base = desc->denoiser.num_layers == 0;   // base LCM: no denoiser tower
     if (!base) {
-        LCM_TRY(check_tower(desc->denoiser, desc->model_dim, "denoiser"));
+        LCM_TRY(check_tower(desc->denoiser, desc->model_dim, desc->dtype, "denoiser"));
         if (desc->denoiser.pos_kind != LCMHIP_POS_NONE && desc->denoiser.pos_kind != LCMHIP_POS_LEARNED)
             return fail(LCMHIP_ERR_UNSUPPORTED, "denoiser: only learned positions (or none) are implemented for the latents");
         // lcm_denoiser.py:441-443 asserts against post-norm; the normformer extras and a residual scale (which
