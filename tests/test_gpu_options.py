@@ -620,7 +620,7 @@ def test_embedding_widths_other_than_1024(D, dtype):
 
 
 @pytest.mark.parametrize("d,heads,dtype", [(512, 4, torch.float32), (512, 4, torch.bfloat16), (1536, 12, torch.float32),
-                                           (1536, 12, torch.bfloat16), (3072, 24, torch.bfloat16)])
+                                           (1536, 12, torch.bfloat16), (3072, 24, torch.bfloat16), (8192, 64, torch.bfloat16)])
 def test_model_widths_outside_the_registered_archs(d, heads, dtype):
     """Model widths and head counts no registered arch uses (the registered ones: 1024 / 8, 2048 / 16, 4096 / 32 and the
     256 / 2 of these tests): other split plans, tile counts and norm-kernel variants, against the oracle.  Weights are
@@ -630,8 +630,9 @@ def test_model_widths_outside_the_registered_archs(d, heads, dtype):
     from oracle.weights import synthetic_noise, synthetic_prompts
     cfg = O.get_arch("mini_two_tower_diffusion_lcm")
     cfg.model_dim = d
+    layers, ffn = (2, 2 * d) if d < 4096 else (1, d)      # the widest admitted model: one layer per tower (7 GB of fp32 weights)
     for t in (cfg.context, cfg.denoiser):
-        t.num_heads, t.ffn_inner_dim, t.use_swiglu, t.num_layers = heads, 2 * d, True, 2
+        t.num_heads, t.ffn_inner_dim, t.use_swiglu, t.num_layers = heads, ffn, True, layers
     sd = O.init_state_dict(cfg, seed=2, mod_gain=6.0, qk_gain=2.0, w_std=0.02 * (1024 / d) ** 0.5)
     norm = {"center": sd["sonar_normalizer.center"], "scale": sd["sonar_normalizer.scale"]}
     x = synthetic_prompts(norm, 3, 4, seed=77)
@@ -645,7 +646,7 @@ def test_model_widths_outside_the_registered_archs(d, heads, dtype):
     mc.model_dim = d
     mc.denoiser.timestep_embed_dim = d
     for t in (mc.context_encoder, mc.denoiser):
-        t.num_attn_heads, t.ffn_inner_dim, t.use_swiglu, t.num_layers = heads, 2 * d, True, 2
+        t.num_attn_heads, t.ffn_inner_dim, t.use_swiglu, t.num_layers = heads, ffn, True, layers
     model = create_two_tower_diffusion_lcm_model(mc, device="cuda:0", dtype=dtype)
     assert set(model.state_dict()) == set(sd)
     model.load_state_dict(sd)
