@@ -1,7 +1,7 @@
 """Probe: 1.6B two-tower, bf16, batch sizes at the row-count boundaries of the product routing (32 / 64 / 128 / 256 /
 384 rows = 2 x documents): every document's first generated sentence against the same document generated alone."""
 import os, sys
-root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
 import torch
 import oracle

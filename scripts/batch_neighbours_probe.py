@@ -1,7 +1,7 @@
 """Follow-up: per-document agreement between neighbouring batch sizes (every document of the smaller batch), first and
 second generated sentence separately, 1.6B bf16."""
 import os, sys
-root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
 import torch
 import oracle
