@@ -509,6 +509,30 @@ def test_random_stopping_patterns(seed):
     assert worst <= FP32_MAX_ABS and cos >= FP32_COS, (worst, cos)
 
 
+def test_more_batch_sizes_than_the_graph_cache_holds():
+    """24 documents with prompts of 1 ... 24 sentences finish one per step, so the session sees 24 different numbers of
+    active documents and records a loop for each; it keeps 16, so the cache is dropped and refilled while the last replay
+    may still be running (the executable graphs are destroyed only after that stream has drained).  On a non-default
+    stream, against the oracle."""
+    arch = "mini_two_tower_diffusion_lcm"
+    B, G = 24, 2
+    lens = list(range(1, B + 1))
+    cfg, sd, x, nz = make_problem(arch, B, B, G, seed=4, prompt_lens=lens)
+    opts = dict(DEFAULT_OPTS, inference_timesteps=5)
+    ref = run_oracle(cfg, sd, x, nz, G, opts, prompt_lens=lens)
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(stream):
+        out, model = run_hip(arch, sd, x, nz, G, opts, prompt_lens=lens)
+        again, _ = run_hip(arch, sd, x, nz, G, opts, prompt_lens=lens, model=model)
+    assert [h[0].seq.shape[0] for h in out.hypotheses] == [n + G for n in lens]
+    worst, cos = compare(out.hypotheses, ref, sd)
+    assert worst <= FP32_MAX_ABS and cos >= FP32_COS, (worst, cos)
+    for ha, hb in zip(out.hypotheses, again.hypotheses):
+        assert torch.equal(ha[0].seq, hb[0].seq)
+    del model
+
+
 def test_teacher_forced_scorer():
     """TwoTowerDiffusionLCMScorer against the oracle's restatement of the reference scorer: ragged documents,
     min_context_len 1 and 3 (with and without a prefill)."""
