@@ -682,3 +682,23 @@ def test_widths_the_operand_stream_cannot_take_are_refused_at_construction():
         t.num_attn_heads = 4
     with pytest.raises(RuntimeError, match="head_dim must be 128"):
         create_two_tower_diffusion_lcm_model(mc, device="cuda:0", dtype=torch.float32)
+
+
+@pytest.mark.parametrize("guidance", [1.0, 3.0])
+def test_sampling_options_in_the_recorded_loop(guidance):
+    """`epsilon_scaling`, a `clip_noise` small enough to bite at every step and another `initial_noise_scale`
+    (generator.py:29-73, builder.py:244-260, 452-454; ddim.py:455-459) through the deterministic loop as a session
+    replays it from its graph (non-default stream), against the oracle."""
+    arch = "mini_two_tower_diffusion_lcm"
+    cfg, sd, x, nz = make_problem(arch, 4, 3, 3, seed=9)
+    opts = dict(DEFAULT_OPTS, inference_timesteps=10, guidance_scale=guidance, epsilon_scaling=1.05, clip_noise=1.2,
+                initial_noise_scale=0.9)
+    trace = []
+    ref = run_oracle(cfg, sd, x, nz, 3, opts, trace=trace)
+    assert any(float(t[1].abs().max()) >= 1.2 - 1e-6 for t in trace)        # the clip really acts on the latents
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(stream):
+        out, _ = run_hip(arch, sd, x, nz, 3, opts)
+    worst, cos = compare(out.hypotheses, ref, sd, start=3)
+    assert worst <= 1e-3 and cos >= 0.9999, (worst, cos)
