@@ -42,6 +42,9 @@ class SchedulerConfig:
     beta_schedule: str = "squaredcos_cap_v2"
     beta_start: float = 1e-4
     beta_end: float = 0.02
+    scaled_linear_exponent: float = 2.0    # ddim.py:87
+    sigmoid_schedule_alpha: float = 1.5    # ddim.py:90-91
+    sigmoid_schedule_beta: float = 0.0
     prediction_type: str = "sample"
     rescale_betas_zero_snr: bool = True
     set_alpha_to_one: bool = True

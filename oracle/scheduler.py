@@ -14,10 +14,20 @@ from torch import Tensor
 from .archs import SchedulerConfig
 
 
-def betas_for_alpha_bar(n: int, max_beta: float = 0.999) -> Tensor:
-    # ddim.py:678-706 (cosine transform only: the archs on the path use squaredcos_cap_v2)
-    def alpha_bar(t: float) -> float:
-        return math.cos((t + 0.008) / 1.008 * math.pi / 2) ** 2
+def betas_for_alpha_bar(n: int, max_beta: float = 0.999, transform: str = "cosine", sigmoid_alpha: float = 1.5,
+                        sigmoid_beta: float = 0.0) -> Tensor:
+    # ddim.py:652-706: "cosine" (the archs on the path use squaredcos_cap_v2) and "sigmoid"
+    if transform == "cosine":
+        def alpha_bar(t: float) -> float:
+            return math.cos((t + 0.008) / 1.008 * math.pi / 2) ** 2
+    elif transform == "sigmoid":
+        # ddim.py:20-27, 683-691: t is clamped as an fp32 torch scalar and x / (1 - x) is an fp32 tensor; math.log and
+        # math.exp then run on its Python float.  t = 1 clamps to 1.0 in fp32: odds inf, alpha_bar 0.
+        def alpha_bar(t: float) -> float:
+            x = torch.clamp(torch.tensor(t), min=1e-32, max=1 - 1e-32)
+            return 1 / (1 + math.exp(-(sigmoid_beta - sigmoid_alpha * math.log(x / (1 - x)))))
+    else:
+        raise ValueError(f"Unsupported alpha_transform_type: {transform}")
 
     betas = [min(1 - alpha_bar((i + 1) / n) / alpha_bar(i / n), max_beta) for i in range(n)]
     return torch.tensor(betas, dtype=torch.float32)
@@ -43,10 +53,14 @@ class DDIMSchedule:
         self.prediction_type = cfg.prediction_type
         if cfg.beta_schedule == "linear":
             betas = torch.linspace(cfg.beta_start, cfg.beta_end, T, dtype=torch.float32)
-        elif cfg.beta_schedule == "scaled_linear":
-            betas = torch.linspace(cfg.beta_start**0.5, cfg.beta_end**0.5, T, dtype=torch.float32) ** 2
+        elif cfg.beta_schedule == "scaled_linear":       # ddim.py:153-164
+            e = cfg.scaled_linear_exponent
+            betas = torch.linspace(cfg.beta_start ** (1 / e), cfg.beta_end ** (1 / e), T, dtype=torch.float32) ** e
         elif cfg.beta_schedule == "squaredcos_cap_v2":
             betas = betas_for_alpha_bar(T)
+        elif cfg.beta_schedule == "sigmoid":             # ddim.py:173-179
+            betas = betas_for_alpha_bar(T, transform="sigmoid", sigmoid_alpha=cfg.sigmoid_schedule_alpha,
+                                        sigmoid_beta=cfg.sigmoid_schedule_beta)
         else:
             raise NotImplementedError(cfg.beta_schedule)
         if cfg.rescale_betas_zero_snr:

@@ -702,3 +702,31 @@ def test_sampling_options_in_the_recorded_loop(guidance):
         out, _ = run_hip(arch, sd, x, nz, 3, opts)
     worst, cos = compare(out.hypotheses, ref, sd, start=3)
     assert worst <= 1e-3 and cos >= 0.9999, (worst, cos)
+
+
+@pytest.mark.parametrize("betas,spacing,pred,extra", [
+    ("sigmoid", "leading", "epsilon", dict(rescale_betas_zero_snr=False, set_alpha_to_one=False)),
+    ("linear", "linspace", "v_prediction", dict(rescale_betas_zero_snr=False)),
+    ("scaled_linear", "trailing", "sample", dict(clip_sample=True, clip_sample_range=2.0, set_alpha_to_one=False)),
+])
+def test_scheduler_variants_end_to_end(betas, spacing, pred, extra):
+    """Scheduler configurations no registered arch uses (DDIMSchedulerConfig, lcm/nn/schedulers/ddim.py:49-133): the
+    other beta schedules and timestep spacings, the model output read as epsilon / velocity (`get_epsilon`, :561-587),
+    x0 clipping, no zero-terminal-SNR rescale, `set_alpha_to_one` off -- generation against the oracle, fp32."""
+    from lcm.models.two_tower_diffusion_lcm import create_two_tower_diffusion_lcm_model
+    from lcm.nn.schedulers import DDIMSchedulerConfig
+    from oracle.archs import SchedulerConfig
+    arch = "mini_two_tower_diffusion_lcm"
+    cfg, sd, x, nz = make_problem(arch, 4, 3, 3, seed=12)
+    cfg.scheduler = SchedulerConfig(num_train_steps=100, beta_schedule=betas, timestep_spacing=spacing, prediction_type=pred, **extra)
+    opts = dict(DEFAULT_OPTS, inference_timesteps=20)
+    ref = run_oracle(cfg, sd, x, nz, 3, opts)
+    mc = mini_config()
+    mc.noise_scheduler = DDIMSchedulerConfig(num_diffusion_train_steps=100, beta_schedule=betas, timestep_spacing=spacing,
+                                             prediction_type=pred, **extra)
+    model = create_two_tower_diffusion_lcm_model(mc, device="cuda:0", dtype=torch.float32)
+    model.load_state_dict(sd)
+    out, _ = run_hip(arch, sd, x, nz, 3, opts, model=model)
+    worst, cos = compare(out.hypotheses, ref, sd, start=3)
+    assert worst <= 1e-3 and cos >= 0.9999, (betas, spacing, pred, worst, cos)
+    del model

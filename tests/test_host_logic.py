@@ -30,6 +30,29 @@ def test_scheduler_tables_equal_the_oracle():
         assert s.alphas_cumprod.shape == (50,) and float(s.alphas_cumprod[-1]) == 0.0
 
 
+@pytest.mark.parametrize("spacing", ["trailing", "leading", "linspace"])
+@pytest.mark.parametrize("betas", ["squaredcos_cap_v2", "linear", "scaled_linear", "sigmoid"])
+def test_scheduler_variants_equal_the_oracle(betas, spacing):
+    """Every beta schedule x timestep spacing of DDIMSchedulerConfig (lcm/nn/schedulers/ddim.py:49-133, 282-356), with
+    and without the zero-terminal-SNR rescale and `set_alpha_to_one`: the host tables of the product equal the oracle's
+    separately written ones."""
+    from lcm.nn.schedulers import DDIMScheduler, DDIMSchedulerConfig
+    for zero_snr in (True, False):
+        for one in (True, False):
+            for T, S in [(100, 40), (1000, 50), (60, 60)]:
+                a = DDIMScheduler(DDIMSchedulerConfig(num_diffusion_train_steps=T, beta_schedule=betas, timestep_spacing=spacing,
+                                                      rescale_betas_zero_snr=zero_snr, set_alpha_to_one=one))
+                a.set_timesteps(S)
+                b = oracle.DDIMSchedule(SchedulerConfig(num_train_steps=T, beta_schedule=betas, timestep_spacing=spacing,
+                                                        rescale_betas_zero_snr=zero_snr, set_alpha_to_one=one))
+                b.set_timesteps(S)
+                tag = (betas, spacing, zero_snr, one, T, S)
+                assert torch.equal(a.timesteps, b.timesteps), tag
+                assert torch.allclose(a.alphas_cumprod, b.alphas_cumprod, rtol=0, atol=0), tag
+                for t in a.timesteps.tolist():
+                    assert a.alpha_pair(int(t)) == tuple(float(v) for v in b._alphas(int(t))), (tag, t)
+
+
 def test_option_defaults_match_reference():
     # lcm/inference/lcm/generator.py:29-58 and lcm/inference/two_tower_diffusion_lcm/generator.py:29-73
     from lcm.inference.two_tower_diffusion_lcm import DiffusionLCMGeneratorOptions
