@@ -533,6 +533,36 @@ def test_more_batch_sizes_than_the_graph_cache_holds():
     del model
 
 
+def test_seed_option_and_device_drawn_noise():
+    """Without `noise=` the draws come from torch.randn on the device, seeded by `options.seed` as the reference seeds
+    them (generator.py:124-125): the same seed gives the same bits, another seed another generation, and a generation
+    with the device's draws handed back in as `noise=` reproduces it."""
+    from lcm.datasets.batch import EmbeddingsBatch
+    from lcm.inference.two_tower_diffusion_lcm import TwoTowerDiffusionLCMGenerator
+    from lcm.models.two_tower_diffusion_lcm import create_two_tower_diffusion_lcm_model
+    from parity_utils import mini_config
+    arch = "mini_two_tower_diffusion_lcm"
+    cfg, sd, x, nz = make_problem(arch, 3, 3, 3)
+    model = create_two_tower_diffusion_lcm_model(mini_config(), device="cuda:0", dtype=torch.float32)
+    model.load_state_dict(sd)
+    batch = EmbeddingsBatch(x.cuda(), None)
+
+    def run(seed):
+        gen = TwoTowerDiffusionLCMGenerator(model, DiffusionLCMGeneratorOptions(**dict(DEFAULT_OPTS, inference_timesteps=10, seed=seed)))
+        return torch.stack([h[0].seq for h in gen(batch, max_gen_len=3).hypotheses])
+
+    a, b, c = run(11), run(11), run(12)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert torch.isfinite(a).all() and torch.equal(a[:, :3], x.cuda())
+    # the same draws, made by hand in the order the generator makes them (one (B, 1, D) draw per sentence)
+    torch.manual_seed(11)
+    draws = torch.stack([torch.randn(3, 1, 1024, device="cuda:0")[:, 0] for _ in range(3)])
+    gen = TwoTowerDiffusionLCMGenerator(model, DiffusionLCMGeneratorOptions(**dict(DEFAULT_OPTS, inference_timesteps=10)))
+    d = torch.stack([h[0].seq for h in gen(batch, max_gen_len=3, noise=draws).hypotheses])
+    assert torch.equal(a, d)
+    del model
+
+
 def test_teacher_forced_scorer():
     """TwoTowerDiffusionLCMScorer against the oracle's restatement of the reference scorer: ragged documents,
     min_context_len 1 and 3 (with and without a prefill)."""
