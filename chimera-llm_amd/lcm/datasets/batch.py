@@ -4,6 +4,7 @@ Mirrors the fields of the reference's lcm/datasets/batch.py:43-70 and the part o
 PaddingMask that callers of this path read (`seq_lens`, `materialize()`).
 """
 
+import copy
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -50,8 +51,41 @@ class EmbeddingsBatch:
     document_lengths: Optional[Tensor] = None
     source_lengths: Optional[Tensor] = None
 
+    def __post_init__(self) -> None:
+        # reference batch.py:73-82: packed documents must fill the sequence (or half of it, for the doubled sequences
+        # of diffusion training)
+        if self.document_lengths is not None:
+            total, width = int(self.document_lengths.sum()), self.seqs.size(1)
+            assert total == width or 2 * total == width, (
+                f"document_lengths {self.document_lengths.tolist()} sum to {total}, but the sequences are "
+                f"{tuple(self.seqs.shape)} (neither their length nor half of it)")
+
     def __len__(self) -> int:
         return self.seqs.size(0)
+
+    def __getitem__(self, i: int):
+        # reference batch.py:104-107 refuses item access too
+        raise NotImplementedError("Access to each item in EmbeddingsBatch not allowed yet")
+
+    def clone(self) -> "EmbeddingsBatch":
+        """A deep copy (reference batch.py:101-102)."""
+        return copy.deepcopy(self)
+
+    def get_last_element(self) -> Tensor:
+        """(B, D): the last unpadded embedding of every sequence (reference batch.py:117-124)."""
+        if self.padding_mask is None:
+            return self.seqs[:, -1]
+        last = self.padding_mask.seq_lens.to(self.seqs.device).long() - 1
+        return self.seqs[torch.arange(self.seqs.size(0), device=self.seqs.device), last]
+
+    def set_last_element(self, element: Tensor) -> None:
+        """Overwrites the last unpadded embedding of every sequence in place (reference batch.py:126-132)."""
+        element = element.to(self.seqs.device)
+        if self.padding_mask is None:
+            self.seqs[:, -1] = element
+            return
+        last = self.padding_mask.seq_lens.to(self.seqs.device).long() - 1
+        self.seqs[torch.arange(self.seqs.size(0), device=self.seqs.device), last] = element.to(self.seqs.dtype)
 
     @property
     def batch_size(self) -> int:

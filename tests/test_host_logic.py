@@ -53,6 +53,40 @@ def test_scheduler_variants_equal_the_oracle(betas, spacing):
                     assert a.alpha_pair(int(t)) == tuple(float(v) for v in b._alphas(int(t))), (tag, t)
 
 
+def test_embeddings_batch_container():
+    """The members of EmbeddingsBatch the reference's callers use (lcm/datasets/batch.py:43-147)."""
+    from lcm.datasets.batch import EmbeddingsBatch, PaddingMask
+    x = torch.arange(2 * 4 * 3, dtype=torch.float32).view(2, 4, 3)
+    b = EmbeddingsBatch(x.clone(), PaddingMask(torch.tensor([4, 2]), 4))
+    assert len(b) == b.batch_size == 2 and b.shape == (2, 4, 3) and b.device == x.device
+    assert [t.shape[0] for t in b.unbatch()] == [4, 2]
+    assert torch.equal(b.get_last_element(), torch.stack([x[0, 3], x[1, 1]]))
+    c = b.clone()
+    c.set_last_element(torch.full((2, 3), -1.0))
+    assert torch.equal(c.seqs[0, 3], torch.full((3,), -1.0)) and torch.equal(c.seqs[1, 1], torch.full((3,), -1.0))
+    assert torch.equal(c.seqs[1, 2:], x[1, 2:]) and torch.equal(b.seqs, x)            # padding untouched; a deep copy
+    d = EmbeddingsBatch(x.clone(), None)
+    assert torch.equal(d.get_last_element(), x[:, -1])
+    d.set_last_element(torch.zeros(2, 3))
+    assert float(d.seqs[:, -1].abs().max()) == 0.0 and torch.equal(d.seqs[:, :-1], x[:, :-1])
+    with pytest.raises(NotImplementedError):
+        b[0]
+    EmbeddingsBatch(x, None, document_lengths=torch.tensor([1, 3]))                   # fills the sequence
+    EmbeddingsBatch(x, None, document_lengths=torch.tensor([2]))                      # half of it (doubled sequences)
+    with pytest.raises(AssertionError):
+        EmbeddingsBatch(x, None, document_lengths=torch.tensor([1, 1, 1]))
+
+    class Shift:
+        def normalize(self, t):
+            return t - 1
+
+        def denormalize(self, t):
+            return t + 1
+    n = b.normalize_seqs(Shift())
+    assert torch.equal(n.seqs, x - 1) and n.padding_mask is b.padding_mask
+    assert torch.equal(n.denormalize_seqs(Shift()).seqs, x) and b.normalize_seqs(None) is b
+
+
 def test_option_defaults_match_reference():
     # lcm/inference/lcm/generator.py:29-58 and lcm/inference/two_tower_diffusion_lcm/generator.py:29-73
     from lcm.inference.two_tower_diffusion_lcm import DiffusionLCMGeneratorOptions
