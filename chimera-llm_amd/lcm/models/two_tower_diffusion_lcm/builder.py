@@ -369,6 +369,7 @@ class DeviceSession:
         """noise: (n_active, D) N(0, 1) draws -> next sentence embedding (n_active, D) fp32.  `variance_noise`
         (n_steps, n_active, D): the per-step draws of stochastic DDIM (needed when the schedule has ddim_eta > 0)."""
         _hip.require_gpu(noise, "noise")
+        self.set_schedule()      # a no-op unless a `denoise_positions` table (model.denoise / forward) replaced the sampling schedule
         nz = noise.float().contiguous()
         assert nz.shape[0] == self.num_active
         out = torch.empty_like(nz)
@@ -703,6 +704,54 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
         return EmbeddingsBatch(out, noisy_batch.padding_mask)
 
     @torch.inference_mode()
+    def denoise(self, noisy_batch: EmbeddingsBatch, context: DeviceContext, source_lengths: Optional[Tensor] = None,
+                cf_guidance_prob: float = 0.0, state_bag: Optional[LCMIncrementalStateBag] = None,
+                inference: bool = False) -> EmbeddingsBatch:
+        """One pass of the denoiser (reference builder.py:193-213; lcm_denoiser.py:152-251): `noisy_batch.seqs`
+        (B, T, D) latents in normalized space with their `diffusion_timesteps` (B, T), conditioned on `context`, the
+        handle `encode` returned for the same B documents.  With `inference` every latent sees the zero vector and the
+        whole context (attention_masks.py:139-140: no cross-attention mask); without it position j sees context
+        positions [0, j + source_length) (the shifted causal mask of the training-shaped forward).  Self-attention is
+        diagonal either way.  Returns the model output (B, T, D) fp32; what it means is the scheduler's
+        `prediction_type`.  `state_bag` is accepted for the reference's signature; the denoiser keeps no state."""
+        if cf_guidance_prob != 0.0:
+            raise NotImplementedError("cf_guidance_prob > 0 drops random conditioning rows (training only); not implemented on the HIP path")
+        sess = getattr(context, "session", None)
+        assert sess is not None, "denoise expects the context handle returned by `encode`"
+        noisy, ts = noisy_batch.seqs, noisy_batch.diffusion_timesteps
+        assert ts is not None, "noisy_batch.diffusion_timesteps is required"
+        assert noisy.dim() == 3 and noisy.shape[0] == sess.num_active, (tuple(noisy.shape), sess.num_active)
+        ts = ts.reshape(noisy.shape[0], noisy.shape[1])
+        uniq, inverse = torch.unique(ts, sorted=True, return_inverse=True)
+        sess.set_schedule(uniq.tolist())      # adaLN table of these timesteps; the sampling loop sets its own again
+        if inference:
+            source_lengths = torch.full((noisy.shape[0],), sess.context_len, dtype=torch.int32, device=noisy.device)
+        out = sess.denoise_positions(noisy, inverse, source_lengths, None)
+        return EmbeddingsBatch(out, noisy_batch.padding_mask)
+
+    @torch.inference_mode()
+    def apply_classifier_free_guidance(self, predicted_noise: Tensor) -> Tensor:
+        """Classifier-free guidance with rescale (reference builder.py:463-488): `predicted_noise` holds the
+        conditional rows in its first half and the unconditional rows in its second; returns the guided half.  This is
+        the arithmetic the sampling loop applies inside its fused DDIM step, reached here through that kernel's
+        entry point: an epsilon-type step from x_t = 0 to alpha_prev = 0 returns the guided prediction unchanged."""
+        assert hasattr(self, "guidance_scale"), (
+            "The model is not properly set for decoding, make sure to call `model.prep_for_denoising()`")
+        _hip.require_gpu(predicted_noise, "predicted noise")
+        cond, uncond = predicted_noise.float().chunk(2)
+        D = cond.shape[-1]
+        c2, u2 = cond.reshape(-1, D).contiguous(), uncond.reshape(-1, D).contiguous()
+        guided = torch.empty_like(c2)
+        params = _hip.DenoiseParams(
+            guidance_scale=float(self.guidance_scale), guidance_rescale=float(self.guidance_rescale), ddim_eta=0.0,
+            epsilon_scaling=0.0, clip_noise=float("inf"), init_noise_sigma=1.0, prediction_type=_hip.PRED["epsilon"],
+            clip_sample=0, clip_sample_range=1.0, thresholding=0, dynamic_thresholding_ratio=0.995, sample_max_value=1.0)
+        _hip.check(_hip.lib.lcmhip_ddim_cfg_step(_hip.ptr(torch.zeros_like(c2)), _hip.ptr(c2), _hip.ptr(u2), _hip.ptr(guided),
+                                                 None, c2.shape[0], D, 0.5, 0.0, C.byref(params), None,
+                                                 _hip.stream_ptr(c2.device)))
+        return guided.reshape(cond.shape).to(predicted_noise.dtype)
+
+    @torch.inference_mode()
     def encode(self, batch: EmbeddingsBatch, state_bag: Optional[LCMIncrementalStateBag] = None,
                *, normalized: bool = True, **kwargs) -> DeviceContext:
         """Contextualizes `batch.seqs` (normalized SONAR embeddings) after what the bag already holds."""
@@ -712,7 +761,9 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
             # reference builder.py:161-191 without a bag: a plain forward over the whole sequence.  A throw-away
             # session that keeps the contextualizer output, so that `.seqs` of the result can be read back.
             B, S = batch.seqs.shape[:2]
-            sess = DeviceSession(self, B, S, 1, keep_context=True)
+            # room for the adaLN table of a `denoise` call on this context: as many timesteps as the sampling schedule
+            steps = len(self.noise_scheduler.timesteps) if getattr(self.noise_scheduler, "timesteps", None) is not None else 1
+            sess = DeviceSession(self, B, S, max(1, steps), keep_context=True)
             sess.reset(B)
             sess.append(batch.seqs, normalized=normalized)
             return DeviceContext(sess, sess.context_len)

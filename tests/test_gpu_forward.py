@@ -108,3 +108,55 @@ def test_forward_1_6b_bf16():
     got, model = _hip_forward(arch, sd, x, noisy, ts, torch.bfloat16, lengths=lengths)
     _check(got, want, lengths, None, 0.999)
     del model
+
+
+def test_model_denoise_and_guidance_methods():
+    """`TwoTowerDiffusionLCModel.denoise` (builder.py:193-213) on the context handle of `encode`: with `inference` every
+    latent sees the whole context (the sampling loop's call, here with three latents per document at different
+    timesteps), without it the shifted causal mask; both against the oracle's denoiser, and the sampling loop still
+    runs on the same session afterwards.  `apply_classifier_free_guidance` (builder.py:463-488) against the oracle."""
+    from lcm.datasets.batch import EmbeddingsBatch
+    from lcm.inference.two_tower_diffusion_lcm import DiffusionLCMGeneratorOptions
+    from lcm.models.two_tower_diffusion_lcm import create_two_tower_diffusion_lcm_model
+    from lcm.nn.incremental_state import LCMIncrementalStateBag
+    from parity_utils import DEFAULT_OPTS, make_problem, mini_config
+    O = oracle
+    arch = "mini_two_tower_diffusion_lcm"
+    cfg, sd, x, nz = make_problem(arch, 3, 6, 1, mod_gain=4.0)
+    om = O.OracleTwoTower(cfg, sd)
+    opts = O.GenOptions(**dict(DEFAULT_OPTS, inference_timesteps=10))
+    om.prep_for_denoising(opts)
+    model = create_two_tower_diffusion_lcm_model(mini_config(), device="cuda:0", dtype=torch.float32)
+    model.load_state_dict(sd)
+    model.prep_for_denoising(DiffusionLCMGeneratorOptions(**dict(DEFAULT_OPTS, inference_timesteps=10)))
+    xn = om.normalize(x)
+    g = torch.Generator().manual_seed(5)
+    noisy = torch.randn(3, 3, 1024, generator=g)
+    ts = torch.tensor([[90, 17, 3], [55, 55, 0], [99, 42, 42]])
+    ctx_ref = om.encode(xn)
+    bag = LCMIncrementalStateBag(16)
+    ctx = model.encode(EmbeddingsBatch(xn.cuda(), None), state_bag=bag)
+    nb = EmbeddingsBatch(noisy.cuda(), None, diffusion_timesteps=ts.cuda())
+    # inference: no cross-attention mask
+    ref = om.denoise(noisy, ts, ctx_ref)
+    out = model.denoise(nb, ctx, inference=True).seqs.cpu()
+    assert (out - ref).abs().max() <= 1e-3 * max(1.0, float(ref.abs().max())), float((out - ref).abs().max())
+    # training shape: position j sees [zero vector, context[: j + source_length]]
+    src = torch.tensor([2, 0, 3])
+    mask = torch.stack([torch.ones(3, 7).tril_(diagonal=int(n)) for n in src]).unsqueeze(1).log()
+    ref2 = om.denoise(noisy, ts, ctx_ref, cross_mask=mask)
+    out2 = model.denoise(nb, ctx, source_lengths=src.cuda()).seqs.cpu()
+    assert (out2 - ref2).abs().max() <= 1e-3 * max(1.0, float(ref2.abs().max()))
+    assert (out2 - out).abs().max() > 1e-3          # the masks differ
+    # the sampling loop on the same session afterwards uses its own schedule again
+    nxt, _ = model.predict_next_sentence(EmbeddingsBatch(x[:, -1:].cuda(), None), ctx, state_bag=LCMIncrementalStateBag(16),
+                                         context_state_bag=bag, noise=nz[0].cuda())
+    assert torch.isfinite(nxt.seqs).all()
+    with pytest.raises(NotImplementedError):
+        model.denoise(nb, ctx, cf_guidance_prob=0.1)
+    # guidance
+    eps = torch.randn(8, 2, 1024, generator=g)
+    want = om.apply_cfg(eps)
+    got = model.apply_classifier_free_guidance(eps.cuda()).cpu()
+    assert got.shape == want.shape and (got - want).abs().max() <= 2e-5 * max(1.0, float(want.abs().max()))
+    del model
