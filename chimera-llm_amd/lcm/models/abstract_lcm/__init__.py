@@ -1,1 +1,1 @@
-from lcm.models.abstract_lcm.builder import AbstractLCModel, AbstractLCModelConfig  # noqa: F401
+from lcm.models.abstract_lcm.builder import AbstractLCModel, AbstractLCModelBuilder, AbstractLCModelConfig  # noqa: F401

@@ -34,3 +34,21 @@ class AbstractLCModel:
 
     def state_dict(self):
         raise NotImplementedError
+
+
+class AbstractLCModelBuilder:
+    """Builds an LCM from its config (reference: abstract_lcm/builder.py:60-106)."""
+
+    def __init__(self, config: AbstractLCModelConfig, *, device=None, dtype: Optional[torch.dtype] = None) -> None:
+        self.config = config
+        self.device, self.dtype = device, dtype
+
+    def build_sonar_normalizer(self):
+        """The normalizer the config names, loaded from its card; None without a name."""
+        if self.config.sonar_normalizer_name is None:
+            return None
+        from lcm.models.sonar_normalizer.loader import load_sonar_normalizer_model
+        return load_sonar_normalizer_model(self.config.sonar_normalizer_name, device=self.device, dtype=self.dtype)
+
+    def build_model(self) -> AbstractLCModel:
+        raise NotImplementedError

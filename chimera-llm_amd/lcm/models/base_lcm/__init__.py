@@ -3,6 +3,7 @@ from lcm.models.base_lcm import archs as _archs  # noqa: F401
 from lcm.models.base_lcm.builder import (  # noqa: F401
     BASE_LCM_MODEL_TYPE,
     BaseLCModel,
+    BaseLCModelBuilder,
     BaseLCModelConfig,
     LCMFrontendConfig,
     ProjectionConfig,

@@ -19,7 +19,7 @@ from torch import Tensor
 from lcm import _hip
 from lcm.nn.weight_norm import fold_weight_norm
 from lcm.datasets.batch import EmbeddingsBatch
-from lcm.models.abstract_lcm import AbstractLCModel, AbstractLCModelConfig
+from lcm.models.abstract_lcm import AbstractLCModel, AbstractLCModelBuilder, AbstractLCModelConfig
 from lcm.models.sonar_normalizer.builder import SonarNormalizer, SonarNormalizerConfig
 from lcm.models.two_tower_diffusion_lcm.builder import (
     TIMESTEP_FREQ_DIM,
@@ -32,6 +32,7 @@ from lcm.models.two_tower_diffusion_lcm.builder import (
     normalizer_spec,
     prelu_spec,
     tower_desc,
+    load_named_normalizer_statistics,
 )
 from lcm.nn.incremental_state import LCMIncrementalStateBag
 from lcm.nn.transformer_config import ProjectionConfig, TransformerConfig
@@ -159,6 +160,7 @@ class BaseLCModel(AbstractLCModel):
             if ncfg.clip_proba is not None:
                 normalizer.clip_min = self._params["frontend.sonar_normalizer.clip_min"]
                 normalizer.clip_max = self._params["frontend.sonar_normalizer.clip_max"]
+            load_named_normalizer_statistics(normalizer, config.sonar_normalizer_name)
         self.frontend = _Frontend(normalizer)
         self.sonar_normalizer = normalizer
         self._handle = C.c_void_p()
@@ -300,6 +302,17 @@ class BaseLCModel(AbstractLCModel):
         """Fills the KV cache with raw prompt positions without computing outputs (what the generator's prefill
         needs: lcm/inference/lcm/generator.py:226-246 discards the prediction)."""
         self._run(batch.seqs, state_bag, normalized=False, noise=None, temperature=0.0, want_output=False)
+
+
+class BaseLCModelBuilder(AbstractLCModelBuilder):
+    """The reference's builder class (base_lcm/builder.py:170-272) as far as it applies here: `build_model` and the
+    inherited `build_sonar_normalizer`; its other `build_*` methods make torch modules, which this implementation does
+    not have."""
+
+    config: BaseLCModelConfig
+
+    def build_model(self) -> "BaseLCModel":
+        return BaseLCModel(self.config, device=self.device, dtype=self.dtype)
 
 
 def create_base_lcm_model(config: BaseLCModelConfig, *, device=None, dtype: Optional[torch.dtype] = None,

@@ -2,8 +2,9 @@
 
 `normalize` / `denormalize` follow the reference's lcm/models/sonar_normalizer/builder.py:121-137
 (centre/scale, optional quantile clipping) and run in the coalesced `lcmhip_normalize` /
-`lcmhip_denormalize` kernels.  The FFT variants (builder.py:58-84) and `fit` (:139-193) are not
-part of the generation path and raise.
+`lcmhip_denormalize` kernels; the packed real FFT of the "*_fft" archs (`FFTInterface`, builder.py:58-84)
+runs in `lcmhip_rfft_pack`.  `fit` (:139-193, scikit-learn on the host) is not part of the generation
+path and raises.
 """
 
 from dataclasses import dataclass
@@ -34,7 +35,20 @@ sonar_normalizer_archs: Dict[str, SonarNormalizerConfig] = {
 }
 
 
-class SonarNormalizer:
+class FFTInterface:
+    """The reference's mix-in (builder.py:58-84): a real FFT over the embedding axis packed into as many real numbers,
+    [Re X_0 .. Re X_{n/2}, Im X_1 .. Im X_{n/2-1}], and its inverse (GPU tensors, widths that are a power of two)."""
+
+    @staticmethod
+    def fft_transform(embeddings: Tensor) -> Tensor:
+        return _hip.rfft_pack(embeddings, inverse=False).to(embeddings.dtype)
+
+    @staticmethod
+    def fft_inverse_transform(embeddings: Tensor) -> Tensor:
+        return _hip.rfft_pack(embeddings, inverse=True).to(embeddings.dtype)
+
+
+class SonarNormalizer(FFTInterface):
     def __init__(self, config: SonarNormalizerConfig, device=None, dtype: Optional[torch.dtype] = None) -> None:
         self.config = config
         dtype = dtype or torch.float32

@@ -6,6 +6,7 @@ from lcm.models.two_tower_diffusion_lcm.builder import (  # noqa: F401
     EncoderFrontendConfig,
     TransformerConfig,
     TwoTowerDiffusionLCModel,
+    TwoTowerDiffusionLCModelBuilder,
     TwoTowerDiffusionLCModelConfig,
     create_two_tower_diffusion_lcm_model,
     lcm_archs,

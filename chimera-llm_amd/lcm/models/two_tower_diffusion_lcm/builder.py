@@ -9,6 +9,7 @@ like the reference's state dict; a `DeviceSession` owns the KV caches and scratc
 """
 
 import ctypes as C
+import os
 import threading
 import math
 import logging
@@ -21,7 +22,7 @@ from torch import Tensor
 from lcm import _hip
 from lcm.nn.weight_norm import fold_weight_norm
 from lcm.datasets.batch import EmbeddingsBatch
-from lcm.models.abstract_lcm import AbstractLCModel, AbstractLCModelConfig
+from lcm.models.abstract_lcm import AbstractLCModel, AbstractLCModelBuilder, AbstractLCModelConfig
 from lcm.models.sonar_normalizer.builder import SonarNormalizer, SonarNormalizerConfig
 from lcm.nn.incremental_state import LCMIncrementalStateBag
 from lcm.nn.schedulers import DDIMScheduler, DDIMSchedulerConfig
@@ -161,6 +162,29 @@ def normalizer_config_for(name: Optional[str], dim: int) -> SonarNormalizerConfi
             arch = sonar_normalizer_archs[card.get("model_arch", "base")]
             cfg = SonarNormalizerConfig(**{**arch.__dict__, "dim": dim})
     return cfg
+
+
+def load_named_normalizer_statistics(normalizer: SonarNormalizer, name: Optional[str]) -> bool:
+    """The reference builds a model around the normalizer its config names, loaded from that normalizer's card with its
+    fitted statistics (abstract_lcm/builder.py:89-101), so a freshly built model already normalizes with them; a
+    checkpoint's own `sonar_normalizer.*` tensors replace them afterwards.  Here: if `name` is a card with a checkpoint of
+    matching shapes, its tensors are copied into the model's normalizer; otherwise the identity statistics stay."""
+    if name is None:
+        return False
+    from lcm.utils.card_utils import resolve_card, resolve_checkpoint_path
+    try:
+        path = resolve_checkpoint_path(resolve_card(name))
+    except ValueError:
+        return False
+    if path is None or not os.path.exists(path):
+        return False
+    blob = torch.load(path, map_location="cpu", weights_only=True)
+    sd = blob["model"] if "model" in blob else blob
+    own = normalizer.state_dict()
+    if any(k not in sd or tuple(sd[k].shape) != tuple(t.shape) for k, t in own.items()):
+        return False
+    normalizer.load_state_dict(sd)
+    return True
 
 
 def normalizer_spec(prefix: str, ncfg: SonarNormalizerConfig) -> List[Tuple[str, Tuple[int, ...], str]]:
@@ -502,6 +526,7 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
         if ncfg.clip_proba is not None:
             self.sonar_normalizer.clip_min = self._params["sonar_normalizer.clip_min"]
             self.sonar_normalizer.clip_max = self._params["sonar_normalizer.clip_max"]
+        load_named_normalizer_statistics(self.sonar_normalizer, config.sonar_normalizer_name)
         self.noise_scheduler = DDIMScheduler(config.noise_scheduler)
         self._handle = C.c_void_p()
         self._bind()
@@ -799,6 +824,21 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
 
     # classifier-free guidance is selected by `prep_for_denoising`; both entry points share the kernel loop
     predict_next_sentence_with_cf_guidance = predict_next_sentence
+
+
+class TwoTowerDiffusionLCModelBuilder(AbstractLCModelBuilder):
+    """The reference's builder class (builder.py:491-608) as far as it applies here: `build_model` (and the inherited
+    `build_sonar_normalizer`).  Its `build_frontend / build_context_encoder / build_denoiser / build_noise_scheduler` make
+    torch modules, which this implementation does not have (the model is a table of device tensors bound to the C
+    library)."""
+
+    config: TwoTowerDiffusionLCModelConfig
+
+    def build_model(self) -> "TwoTowerDiffusionLCModel":
+        return TwoTowerDiffusionLCModel(self.config, device=self.device, dtype=self.dtype)
+
+    def build_noise_scheduler(self) -> DDIMScheduler:
+        return DDIMScheduler(self.config.noise_scheduler)
 
 
 def create_two_tower_diffusion_lcm_model(config: TwoTowerDiffusionLCModelConfig, *, device=None,

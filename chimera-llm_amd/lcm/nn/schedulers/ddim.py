@@ -69,6 +69,27 @@ def _zero_terminal_snr(betas: Tensor) -> Tensor:
     return 1 - torch.cat([bar[0:1], bar[1:] / bar[:-1]])
 
 
+def betas_for_alpha_bar(num_diffusion_timesteps: int, max_beta: float = 0.999,
+                        alpha_transform_type: Literal["cosine", "exp", "sigmoid"] = "cosine",
+                        sigmoid_alpha: float = 1.5, sigmoid_beta: float = 0) -> Tensor:
+    """Betas that discretize an alpha-bar function of t in [0, 1] (reference ddim.py:652-706): the cosine, sigmoid
+    and exponential transforms under the reference's name and arguments."""
+    n = num_diffusion_timesteps
+    if alpha_transform_type == "cosine":
+        return _cosine_betas(n, max_beta)
+    if alpha_transform_type == "sigmoid":
+        return _sigmoid_betas(n, sigmoid_alpha, sigmoid_beta, max_beta)
+    if alpha_transform_type == "exp":
+        bar = [math.exp(i / n * -12.0) for i in range(n + 1)]
+        return torch.tensor([min(1 - bar[i + 1] / bar[i], max_beta) for i in range(n)], dtype=torch.float32)
+    raise ValueError(f"Unsupported alpha_transform_type: {alpha_transform_type}")
+
+
+def rescale_zero_terminal_snr(betas: Tensor) -> Tensor:
+    """Betas rescaled to zero terminal SNR (reference ddim.py:709-741; arXiv 2305.08891, algorithm 1)."""
+    return _zero_terminal_snr(betas)
+
+
 class DDIMScheduler:
     def __init__(self, config: DDIMSchedulerConfig):
         self.config = config
@@ -124,6 +145,21 @@ class DDIMScheduler:
         a_t = float(self.alphas_cumprod[int(timestep)])
         a_prev = float(self.alphas_cumprod[prev]) if prev >= 0 else float(self.final_alpha_cumprod)
         return a_t, a_prev
+
+    # ---- host tables of the reference's analysis helpers (ddim.py:209-240) ---------------------------------------
+    def _get_variance(self, timestep, prev_timestep):
+        a_t = self.alphas_cumprod[timestep]
+        a_prev = self.alphas_cumprod[prev_timestep] if prev_timestep >= 0 else self.final_alpha_cumprod
+        return ((1 - a_prev) / (1 - a_t)) * (1 - a_t / a_prev)
+
+    def get_variances(self) -> Tensor:
+        """The DDIM variance of every training step against its predecessor (the first against `final_alpha_cumprod`)."""
+        a_t = self.alphas_cumprod
+        a_prev = torch.cat((torch.tensor([self.final_alpha_cumprod]), a_t[:-1]))
+        return ((1 - a_prev) / (1 - a_t)) * (1 - a_t / a_prev)
+
+    def get_snrs(self) -> Tensor:
+        return self.alphas_cumprod / (1 - self.alphas_cumprod)
 
     def _params(self, eta, epsilon_scaling, prediction_type, clip_noise=float("inf")) -> "_hip.DenoiseParams":
         return _hip.DenoiseParams(

@@ -66,3 +66,30 @@ def test_strict_loading_errors():
     bad["denoiser.final_proj.fc.bias"] = torch.zeros(7)
     with pytest.raises(RuntimeError, match="shape mismatch"):
         model.load_state_dict(bad)
+
+
+def test_fresh_models_carry_their_normalizer_card_statistics():
+    """abstract_lcm/builder.py:89-101: a model is built around the normalizer its config names, loaded from that card, so
+    `create_*_model` / the builder classes return a model that already normalizes with the fitted statistics.  (The
+    seeded `init_parameters` of this package resets every tensor, the statistics included.)  The normalizer's
+    FFTInterface methods are the packed transform of the "*_fft" archs."""
+    from lcm.models.base_lcm import BaseLCModelBuilder, lcm_archs as base_archs
+    from lcm.models.two_tower_diffusion_lcm import TwoTowerDiffusionLCModelBuilder, create_two_tower_diffusion_lcm_model, lcm_archs
+    dummy = oracle.load_dummy_normalizer()
+    cfg = lcm_archs.get_config("toy_two_tower_diffusion_lcm")
+    for model in (create_two_tower_diffusion_lcm_model(cfg, device="cuda:0"),
+                  TwoTowerDiffusionLCModelBuilder(cfg, device="cuda:0", dtype=torch.float32).build_model()):
+        assert torch.equal(model.sonar_normalizer.center.cpu(), dummy["center"])
+        assert torch.equal(model.state_dict()["sonar_normalizer.scale"].cpu(), dummy["scale"])
+        x = torch.randn(3, 1024, device="cuda:0") * 0.01
+        assert torch.allclose(model.sonar_normalizer.normalize(x).cpu(), (x.cpu() - dummy["center"]) / dummy["scale"], atol=1e-4)
+        model.init_parameters(seed=1)
+        assert float(model.sonar_normalizer.center.abs().max()) == 0.0
+    bcfg = base_archs.get_config("toy_base_lcm")
+    bcfg.sonar_normalizer_name = "dummy_sonar_normalizer"
+    base = BaseLCModelBuilder(bcfg, device="cuda:0", dtype=torch.float32).build_model()
+    assert torch.equal(base.sonar_normalizer.scale.cpu(), dummy["scale"])
+    n = base.sonar_normalizer
+    v = torch.randn(2, 1024, device="cuda:0")
+    assert (n.fft_inverse_transform(n.fft_transform(v)) - v).abs().max() <= 1e-5
+    assert (n.fft_transform(v).cpu() - oracle.model.fft_transform(v.cpu())).abs().max() <= 1e-4

@@ -3,6 +3,8 @@ naming, cards, containers, and the refusal to run without a GPU."""
 
 import dataclasses
 
+import math
+
 import pytest
 import torch
 
@@ -85,6 +87,60 @@ def test_embeddings_batch_container():
     n = b.normalize_seqs(Shift())
     assert torch.equal(n.seqs, x - 1) and n.padding_mask is b.padding_mask
     assert torch.equal(n.denormalize_seqs(Shift()).seqs, x) and b.normalize_seqs(None) is b
+
+
+def test_scheduler_analysis_tables_and_module_functions():
+    """`get_variances`, `get_snrs`, `_get_variance` (ddim.py:209-240) and the module functions `betas_for_alpha_bar` /
+    `rescale_zero_terminal_snr` (:652-741) under the reference's names."""
+    from lcm.nn.schedulers import DDIMScheduler, DDIMSchedulerConfig
+    from lcm.nn.schedulers.ddim import betas_for_alpha_bar, rescale_zero_terminal_snr
+    s = DDIMScheduler(DDIMSchedulerConfig(num_diffusion_train_steps=100, rescale_betas_zero_snr=False, set_alpha_to_one=False))
+    ac = s.alphas_cumprod.double()
+    v = s.get_variances()
+    assert v.shape == (100,) and float(v[0]) == 0.0                       # its own predecessor: alpha_0 / alpha_0
+    for t in (1, 17, 99):
+        want = (1 - ac[t - 1]) / (1 - ac[t]) * (1 - ac[t] / ac[t - 1])
+        assert abs(float(v[t]) - float(want)) <= 1e-6 and abs(float(s._get_variance(t, t - 1)) - float(want)) <= 1e-6
+    assert abs(float(s._get_variance(5, -1)) - float((1 - ac[0]) / (1 - ac[5]) * (1 - ac[5] / ac[0]))) <= 1e-6
+    assert torch.allclose(s.get_snrs().double(), ac / (1 - ac), rtol=1e-6)
+    assert torch.equal(betas_for_alpha_bar(100), s.betas)
+    assert torch.equal(betas_for_alpha_bar(50, alpha_transform_type="sigmoid", sigmoid_alpha=1.5, sigmoid_beta=0),
+                       DDIMScheduler(DDIMSchedulerConfig(num_diffusion_train_steps=50, beta_schedule="sigmoid",
+                                                         rescale_betas_zero_snr=False)).betas)
+    e = betas_for_alpha_bar(10, alpha_transform_type="exp")
+    assert torch.allclose(e, torch.full((10,), 1 - math.exp(-1.2)), atol=1e-6)
+    with pytest.raises(ValueError):
+        betas_for_alpha_bar(10, alpha_transform_type="other")
+    z = rescale_zero_terminal_snr(s.betas)
+    assert float(torch.cumprod(1 - z, 0)[-1]) == 0.0 and abs(float(z[0]) - float(s.betas[0])) <= 1e-7
+    assert torch.equal(z, DDIMScheduler(DDIMSchedulerConfig(num_diffusion_train_steps=100)).betas)
+
+
+def test_builder_classes_and_named_normalizer_statistics():
+    """The reference's builder classes (abstract_lcm/builder.py:60-106, two_tower_diffusion_lcm/builder.py:491-608,
+    base_lcm/builder.py:170-272) and the rule that a model is built with the fitted statistics of the normalizer card it
+    names (abstract_lcm/builder.py:89-101)."""
+    from lcm.models.abstract_lcm import AbstractLCModelBuilder, AbstractLCModelConfig
+    from lcm.models.base_lcm import BaseLCModelBuilder
+    from lcm.models.sonar_normalizer.builder import SonarNormalizer, SonarNormalizerConfig
+    from lcm.models.two_tower_diffusion_lcm import TwoTowerDiffusionLCModelBuilder, lcm_archs
+    from lcm.models.two_tower_diffusion_lcm.builder import load_named_normalizer_statistics
+    assert issubclass(TwoTowerDiffusionLCModelBuilder, AbstractLCModelBuilder) and issubclass(BaseLCModelBuilder, AbstractLCModelBuilder)
+    assert AbstractLCModelBuilder(AbstractLCModelConfig()).build_sonar_normalizer() is None
+    with pytest.raises(NotImplementedError):
+        AbstractLCModelBuilder(AbstractLCModelConfig()).build_model()
+    b = TwoTowerDiffusionLCModelBuilder(lcm_archs.get_config("toy_two_tower_diffusion_lcm"), device="cpu")
+    assert b.build_noise_scheduler().alphas_cumprod.shape == (1000,)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        b.build_model()
+    dummy = oracle.load_dummy_normalizer()
+    n = SonarNormalizer(SonarNormalizerConfig())
+    assert load_named_normalizer_statistics(n, "dummy_sonar_normalizer")
+    assert torch.equal(n.center, dummy["center"]) and torch.equal(n.scale, dummy["scale"])
+    fresh = SonarNormalizer(SonarNormalizerConfig())
+    assert not load_named_normalizer_statistics(fresh, None) and not load_named_normalizer_statistics(fresh, "no_such_card")
+    assert not load_named_normalizer_statistics(SonarNormalizer(SonarNormalizerConfig(dim=768)), "dummy_sonar_normalizer")
+    assert float(fresh.center.abs().max()) == 0.0 and float((fresh.scale - 1).abs().max()) == 0.0
 
 
 def test_option_defaults_match_reference():
