@@ -90,8 +90,8 @@ typedef struct lcmhip_session lcmhip_session;
 /* One transformer stack (contextualizer or denoiser); lcm/nn/transformer/factory.py:47-123. */
 typedef struct {
     int32_t num_layers;
-    int32_t num_heads;     /* model_dim / num_heads must be 128 */
-    int32_t ffn_dim;       /* inner width actually allocated (after GLU rounding) */
+    int32_t num_heads;     /* model_dim / num_heads must be 128; 2 or a multiple of 4 heads */
+    int32_t ffn_dim;       /* inner width actually allocated (after GLU rounding); a multiple of 128 (fp32) / 256 (bf16) */
     int32_t norm_kind;     /* LCMHIP_NORM_* */
     int32_t ffn_kind;      /* LCMHIP_FFN_*  */
     int32_t pos_kind;      /* LCMHIP_POS_*  */
@@ -110,10 +110,10 @@ typedef struct {
 
 /* lcm/models/two_tower_diffusion_lcm/builder.py:49-81 (TwoTowerDiffusionLCModelConfig). */
 typedef struct {
-    int32_t sonar_dim;         /* 1024 */
-    int32_t model_dim;
+    int32_t sonar_dim;         /* 1024 for SONAR; any multiple of 128 (fp32) / 256 (bf16) up to 4096 */
+    int32_t model_dim;         /* a multiple of 256 up to 8192 */
     int32_t max_seq_len;
-    int32_t timestep_freq_dim; /* 256, lcm/nn/timestep_encoder.py:28 */
+    int32_t timestep_freq_dim; /* 256, lcm/nn/timestep_encoder.py:28; a multiple of 128 (fp32) / 256 (bf16) */
     int32_t dtype;             /* LCMHIP_F32 or LCMHIP_BF16: dtype of every bound weight and of GEMM operands */
     float norm_eps;
     lcmhip_tower_desc context;   /* two-tower: the contextualizer; base LCM: the causal decoder ("lcm") */
