@@ -610,3 +610,29 @@ def test_gemm_activation_epilogues(hip, dtype, act):
     rc = hip.lib.lcmhip_gemm(hip.ptr(A), K, hip.ptr(W), None, None, None, None, hip.ptr(out), N, M, N, K,
                              hip.EPI_STORE | (hip.ACT["gelu"] << 8), hip.dtype_code(dtype), None, 0, _st(hip))
     assert rc == -1
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_stand_alone_timestep_encoder(dtype):
+    """`lcm.nn.timestep_encoder.DiTTimestepEncoder` (lcm/nn/timestep_encoder.py:18-122) used by itself: sinusoidal
+    frequencies, Linear, SiLU, Linear through `lcmhip_gemm`, against the oracle's `embed_time` on the same weights."""
+    import oracle as O
+    from lcm.nn.timestep_encoder import DiTTimestepEncoder
+    cfg = O.get_arch("toy_two_tower_diffusion_lcm")
+    sd = O.init_state_dict(cfg, seed=3, t_gain=3.0)
+    enc = DiTTimestepEncoder(1024, device="cuda:0", dtype=dtype)
+    assert set(enc.state_dict()) == {"fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias"}
+    assert float(enc.state_dict()["fc1.bias"].abs().max()) == 0.0 and 0.015 < float(enc.state_dict()["fc2.weight"].float().std()) < 0.025
+    enc.load_state_dict({k[len("denoiser.embed_time."):]: v for k, v in sd.items() if k.startswith("denoiser.embed_time.")})
+    ts = torch.tensor([[0, 1, 17], [250, 999, 500]])
+    if dtype == torch.bfloat16:
+        sd = {k: v.bfloat16().float() for k, v in sd.items()}
+    ref = O.OracleTwoTower(cfg, sd).embed_time(ts)
+    out = enc(ts.cuda())
+    assert out.shape == (2, 3, 1024) and out.dtype == dtype
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert (out.float().cpu() - ref).abs().max() <= tol * max(1.0, float(ref.abs().max()))
+    emb = DiTTimestepEncoder.sinusoidal_timestep_embedding(torch.tensor([3.0, 7.5]), 7)
+    assert emb.shape == (2, 7) and float(emb[:, -1].abs().max()) == 0.0 and abs(float(emb[0, 0]) - math.cos(3.0)) < 1e-6
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        DiTTimestepEncoder(1024, device="cpu")
