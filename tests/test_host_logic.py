@@ -143,6 +143,33 @@ def test_builder_classes_and_named_normalizer_statistics():
     assert float(fresh.center.abs().max()) == 0.0 and float((fresh.scale - 1).abs().max()) == 0.0
 
 
+def test_reference_import_paths_of_the_configuration_types():
+    """Callers of the reference import its configuration types from the modules that define them there; the same
+    paths resolve here to the same classes the builders use."""
+    from lcm.models.base_lcm import BaseLCModelConfig
+    from lcm.models.base_lcm.frontend import LCMFrontendConfig
+    from lcm.models.two_tower_diffusion_lcm import TwoTowerDiffusionLCModelConfig
+    from lcm.models.two_tower_diffusion_lcm.frontend import EncoderFrontendConfig
+    from lcm.nn.denoisers import DenoiserConfig
+    from lcm.nn.denoisers.factory import DenoiserConfig as D2
+    from lcm.nn.initialization import SONAR_STD, SUPPORTED_INIT_TYPES, activation_code
+    from lcm.nn.normalization import SUPPORTED_LN_TYPES, norm_kind
+    from lcm.nn.projection import ProjectionConfig
+    from lcm.nn.schedulers import DDIMScheduler, DDIMSchedulerConfig, DDIMSchedulerOutput  # noqa: F401
+    from lcm.nn.transformer import TransformerConfig
+    from lcm.nn.transformer.factory import TransformerConfig as T2
+    cfg = TwoTowerDiffusionLCModelConfig()
+    assert type(cfg.context_encoder) is TransformerConfig is T2 and type(cfg.denoiser) is DenoiserConfig is D2
+    assert type(cfg.frontend) is EncoderFrontendConfig and type(cfg.denoiser.pre_denoiser) is ProjectionConfig
+    assert type(BaseLCModelConfig().frontend) is LCMFrontendConfig and LCMFrontendConfig().embedding_std == SONAR_STD == 0.006
+    assert set(SUPPORTED_LN_TYPES.__args__) == {"standard", "fp32", "rms", "unit"} and "sonar" in SUPPORTED_INIT_TYPES.__args__
+    assert [norm_kind(n) for n in ("standard", "rms", "fp32", "unit")] == [0, 1, 2, 3] and activation_code(None) is None
+    assert activation_code("relu") == 0 and activation_code("silu") == 6
+    for bad in (lambda: norm_kind("batch"), lambda: activation_code("swish")):
+        with pytest.raises(ValueError):
+            bad()
+
+
 def test_option_defaults_match_reference():
     # lcm/inference/lcm/generator.py:29-58 and lcm/inference/two_tower_diffusion_lcm/generator.py:29-73
     from lcm.inference.two_tower_diffusion_lcm import DiffusionLCMGeneratorOptions
