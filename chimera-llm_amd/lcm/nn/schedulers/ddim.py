@@ -200,11 +200,25 @@ class DDIMScheduler:
         return DDIMSchedulerOutput(prev, x0)
 
     def get_epsilon(self, model_output: Tensor, sample: Tensor, timestep) -> Tensor:
-        a_t = self.alphas_cumprod[int(timestep)].item()
+        """The noise the model output implies for `sample` at `timestep` under the scheduler's prediction type
+        (reference ddim.py:561-587), fp32.  Computed by the step kernel: with alpha_prev = 0 a deterministic DDIM step
+        returns sqrt(0) x0 + sqrt(1) epsilon, i.e. the predicted noise itself."""
         if self.prediction_type == "epsilon":
             return model_output
-        if self.prediction_type == "sample":
-            return (sample - a_t**0.5 * model_output) / (1 - a_t) ** 0.5
-        if self.prediction_type == "v_prediction":
-            return a_t**0.5 * model_output + (1 - a_t) ** 0.5 * sample
-        raise ValueError(f"unknown prediction type {self.prediction_type}")
+        if self.prediction_type not in ("sample", "v_prediction"):
+            raise ValueError(
+                f"prediction_type given as {self.prediction_type} must be one of `epsilon`, `sample`, or `v_prediction`")
+        _hip.require_gpu(sample, "sample")
+        x = sample.float().contiguous()
+        out = model_output.float().contiguous()
+        assert out.shape == x.shape, (tuple(out.shape), tuple(x.shape))
+        dim = x.shape[-1]
+        eps = torch.empty_like(x)
+        p = _hip.DenoiseParams(
+            guidance_scale=1.0, guidance_rescale=0.0, ddim_eta=0.0, epsilon_scaling=0.0, clip_noise=3.0e38,
+            init_noise_sigma=1.0, prediction_type=_hip.PRED[self.prediction_type], clip_sample=0, clip_sample_range=1.0,
+            thresholding=0, dynamic_thresholding_ratio=0.995, sample_max_value=1.0)
+        _hip.check(_hip.lib.lcmhip_ddim_cfg_step(_hip.ptr(x), _hip.ptr(out), None, _hip.ptr(eps), None, x.numel() // dim, dim,
+                                                 float(self.alphas_cumprod[int(timestep)]), 0.0, p, None,
+                                                 _hip.stream_ptr(x.device)))
+        return eps

@@ -636,3 +636,21 @@ def test_stand_alone_timestep_encoder(dtype):
     assert emb.shape == (2, 7) and float(emb[:, -1].abs().max()) == 0.0 and abs(float(emb[0, 0]) - math.cos(3.0)) < 1e-6
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         DiTTimestepEncoder(1024, device="cpu")
+
+
+@pytest.mark.parametrize("pred", ["sample", "v_prediction", "epsilon"])
+def test_scheduler_get_epsilon(pred):
+    """`DDIMScheduler.get_epsilon` of the product (ddim.py:561-587) against the oracle's scheduler, at an ordinary
+    timestep and at the last training step, where the zero-terminal-SNR schedule has alpha_bar = 0."""
+    import oracle as O
+    from lcm.nn.schedulers import DDIMScheduler, DDIMSchedulerConfig
+    from oracle.archs import SchedulerConfig
+    a = DDIMScheduler(DDIMSchedulerConfig(num_diffusion_train_steps=100, prediction_type=pred))
+    b = O.DDIMSchedule(SchedulerConfig(num_train_steps=100, prediction_type=pred))
+    g = torch.Generator().manual_seed(3)
+    x, out = torch.randn(5, 2, 1024, generator=g), torch.randn(5, 2, 1024, generator=g)
+    for t in (37, 99):
+        want = b.get_epsilon(out, x, t)
+        got = a.get_epsilon(out.cuda(), x.cuda(), t).cpu()
+        assert got.shape == want.shape and torch.isfinite(got).all()
+        assert (got - want).abs().max() <= 1e-5 * max(1.0, float(want.abs().max())), (pred, t)
