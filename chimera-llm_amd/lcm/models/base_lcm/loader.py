@@ -4,7 +4,19 @@ checkpoints is stripped as at :24-30)."""
 import torch
 
 from lcm.models.base_lcm.builder import BaseLCModel, BaseLCModelConfig, lcm_archs
-from lcm.models.two_tower_diffusion_lcm.loader import _apply_overrides
+from lcm.models.two_tower_diffusion_lcm.loader import _apply_overrides, convert_lcm_checkpoint  # noqa: F401
+
+
+def load_base_lcm_config(name_or_card) -> BaseLCModelConfig:
+    """The configuration a card describes: its `model_arch` with the card's `model_config` overrides applied
+    (the reference's StandardModelConfigLoader, loader.py:33-37)."""
+    from lcm.utils.card_utils import resolve_card
+
+    card = resolve_card(name_or_card)
+    config: BaseLCModelConfig = lcm_archs.get_config(card.get("model_arch", "toy_base_lcm"))
+    if card.get("model_config"):
+        _apply_overrides(config, card["model_config"])
+    return config
 
 
 def load_base_lcm_model(name_or_card, device=None, dtype=None) -> BaseLCModel:
@@ -12,9 +24,7 @@ def load_base_lcm_model(name_or_card, device=None, dtype=None) -> BaseLCModel:
     from lcm.utils.card_utils import resolve_card, resolve_checkpoint_path
 
     card = resolve_card(name_or_card)
-    config: BaseLCModelConfig = lcm_archs.get_config(card.get("model_arch", "toy_base_lcm"))
-    if card.get("model_config"):
-        _apply_overrides(config, card["model_config"])
+    config = load_base_lcm_config(card)
     model = BaseLCModel(config, device=device, dtype=dtype, seed=card.get("seed"))
     ckpt = resolve_checkpoint_path(card)
     has_normalizer = False

@@ -26,15 +26,32 @@ def _apply_overrides(obj: Any, overrides: Dict[str, Any]) -> Any:
     return obj
 
 
+def load_two_tower_diffusion_lcm_config(name_or_card) -> TwoTowerDiffusionLCModelConfig:
+    """The configuration a card describes: its `model_arch` with the card's `model_config` overrides applied
+    (the reference's StandardModelConfigLoader, loader.py:19-23)."""
+    from lcm.utils.card_utils import resolve_card
+
+    card = resolve_card(name_or_card)
+    config: TwoTowerDiffusionLCModelConfig = lcm_archs.get_config(card.get("model_arch", "toy_two_tower_diffusion_lcm"))
+    if card.get("model_config"):
+        _apply_overrides(config, card["model_config"])
+    return config
+
+
+def convert_lcm_checkpoint(checkpoint: Dict[str, Any], config: Any = None) -> Dict[str, Any]:
+    """DDP checkpoints: the `module.` prefix of the state-dict keys is removed in place (base_lcm/loader.py:24-30)."""
+    sd = checkpoint["model"]
+    for k in [k for k in sd if k.startswith("module.")]:
+        sd[k[len("module."):]] = sd.pop(k)
+    return checkpoint
+
+
 def load_two_tower_diffusion_lcm_model(name_or_card, device=None, dtype=None) -> TwoTowerDiffusionLCModel:
     from lcm.models.sonar_normalizer.loader import load_sonar_normalizer_model
     from lcm.utils.card_utils import resolve_card, resolve_checkpoint_path
 
     card = resolve_card(name_or_card)
-    arch = card.get("model_arch", "toy_two_tower_diffusion_lcm")
-    config: TwoTowerDiffusionLCModelConfig = lcm_archs.get_config(arch)
-    if card.get("model_config"):
-        _apply_overrides(config, card["model_config"])
+    config = load_two_tower_diffusion_lcm_config(card)
     model = TwoTowerDiffusionLCModel(config, device=device, dtype=dtype, seed=card.get("seed"))
     ckpt = resolve_checkpoint_path(card)
     if ckpt is not None:

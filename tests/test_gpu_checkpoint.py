@@ -93,3 +93,35 @@ def test_fresh_models_carry_their_normalizer_card_statistics():
     v = torch.randn(2, 1024, device="cuda:0")
     assert (n.fft_inverse_transform(n.fft_transform(v)) - v).abs().max() <= 1e-5
     assert (n.fft_transform(v).cpu() - oracle.model.fft_transform(v.cpu())).abs().max() <= 1e-4
+
+
+def test_training_directory_and_checkpoint_path_as_model_names(tmp_path):
+    """`load_model_from_card` given a training directory (last checkpoint) or a `checkpoints/step_<n>/model.pt` inside one,
+    and `load_model_with_overrides` for a directory with a card beside the checkpoint and for an old-style directory with
+    `config_logs/all_config.yaml` (card_utils.py:72-125, 178-223): the weights of the right step arrive in the model."""
+    from lcm.utils.card_utils import load_model_from_card, load_model_with_overrides
+    arch = "toy_base_lcm"
+    cfg = oracle.get_base_arch(arch)
+    sds = {}
+    for step in (10, 20):
+        sds[step] = oracle.init_state_dict(cfg, seed=step)
+        d = tmp_path / "run" / "checkpoints" / f"step_{step}"
+        d.mkdir(parents=True)
+        torch.save({"model": {"module." + k: v for k, v in sds[step].items()}}, d / "model.pt")
+        yaml.safe_dump({"name": f"run_step{step}", "model_family": "base_lcm", "model_arch": arch,
+                        "checkpoint": "file://" + str(d / "model.pt")}, open(d / "model_card.yaml", "w"))
+    key = "lcm.layers.1.ffn.inner_proj.weight"
+    m = load_model_from_card(str(tmp_path / "run"), device="cuda:0", dtype=torch.float32)
+    assert torch.equal(m.state_dict()[key].cpu(), sds[20][key])
+    m = load_model_from_card(str(tmp_path / "run" / "checkpoints" / "step_10" / "model.pt"), device="cuda:0", dtype=torch.float32)
+    assert torch.equal(m.state_dict()[key].cpu(), sds[10][key])
+    m = load_model_with_overrides(tmp_path / "run", step=10, device="cuda:0", dtype=torch.float32)
+    assert torch.equal(m.state_dict()[key].cpu(), sds[10][key])
+    old = tmp_path / "old_run"
+    (old / "config_logs").mkdir(parents=True)
+    torch.save({"model": sds[20]}, old / "model.pt")
+    yaml.safe_dump({"trainer": {"model_config_or_name": {"lcm": {"num_layers": 2}}}}, open(old / "config_logs" / "all_config.yaml", "w"))
+    m = load_model_with_overrides(old, model_type="base_lcm", device="cuda:0", dtype=torch.float32)
+    assert torch.equal(m.state_dict()[key].cpu(), sds[20][key])
+    with pytest.raises(ValueError, match="not a valid model directory"):
+        load_model_with_overrides(tmp_path / "nothing_here", model_type="base_lcm")

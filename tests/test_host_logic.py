@@ -170,6 +170,61 @@ def test_reference_import_paths_of_the_configuration_types():
             bad()
 
 
+def test_card_utilities_and_model_type_registry(tmp_path):
+    """The host-side card functions of lcm/utils/card_utils.py:28-175 and the registry of
+    lcm/utils/model_type_registry.py:9-72 (no model is built here)."""
+    import yaml
+    from lcm.models.base_lcm import BaseLCModelConfig, TransformerConfig
+    from lcm.models.base_lcm.loader import convert_lcm_checkpoint, load_base_lcm_config
+    from lcm.models.sonar_normalizer.loader import load_sonar_normalizer_config
+    from lcm.models.two_tower_diffusion_lcm.loader import load_two_tower_diffusion_lcm_config
+    from lcm.utils.card_utils import (create_model_card, create_model_card_from_training_folder, resolve_card,
+                                      resolve_checkpoint_path, save_model_card)
+    from lcm.utils.model_type_registry import ModelTypeConfig, ModelTypeRegistry, lcm_model_type_registry
+    # registry
+    cfg = lcm_model_type_registry.get_config("two_tower_diffusion_lcm")
+    assert isinstance(cfg, ModelTypeConfig) and cfg.model_loader is lcm_model_type_registry.get_model_loader("two_tower_diffusion_lcm")
+    assert cfg.config_loader is load_two_tower_diffusion_lcm_config and callable(cfg.model_factory)
+    reg = ModelTypeRegistry()
+    reg.register(ModelTypeConfig("x", config_loader=len, model_factory=len, model_loader=max))
+    reg.register("y", min)
+    assert reg.get_model_loader("x") is max and reg.get_model_loader("y") is min
+    with pytest.raises(ValueError, match="already registered"):
+        reg.register("x", min)
+    with pytest.raises(ValueError, match="does not contain"):
+        reg.get_config("z")
+    # cards made on the fly: a dataclass configuration, saved and read back
+    card = create_model_card(tmp_path / "model.pt", BaseLCModelConfig(model_dim=256, lcm=TransformerConfig(num_layers=3, num_attn_heads=2)),
+                             "base_lcm", model_name="card_a", model_arch="toy_base_lcm")
+    assert resolve_card("card_a")["model_config"]["lcm"]["num_layers"] == 3
+    loaded = load_base_lcm_config("card_a")
+    assert loaded.model_dim == 256 and loaded.lcm.num_layers == 3 and loaded.lcm.num_attn_heads == 2
+    save_model_card(card, tmp_path / "saved.yaml")
+    back = yaml.safe_load(open(tmp_path / "saved.yaml"))
+    assert back["name"] == "card_a" and back["model_family"] == "base_lcm" and back["checkpoint"].endswith("/model.pt")
+    assert resolve_checkpoint_path(resolve_card(str(tmp_path / "saved.yaml"))) == str(tmp_path / "model.pt")
+    two = create_model_card(None, {"trained_with_cf_guidance": True, "denoiser": {"num_layers": 4}}, "two_tower_diffusion_lcm",
+                            model_name="card_b", model_arch="toy_two_tower_diffusion_lcm")
+    c2 = load_two_tower_diffusion_lcm_config(two)
+    assert c2.trained_with_cf_guidance and c2.denoiser.num_layers == 4 and c2.context_encoder.num_layers == 2
+    assert load_sonar_normalizer_config("dummy_sonar_normalizer").dim == 1024
+    # a training folder as the reference's trainer leaves it
+    for step in (10, 20):
+        d = tmp_path / "run" / "checkpoints" / f"step_{step}"
+        d.mkdir(parents=True)
+        yaml.safe_dump({"name": f"step{step}", "model_family": "base_lcm", "model_arch": "toy_base_lcm",
+                        "checkpoint": "file:///somewhere/else.pt", "model_config": {"model_dim": 256}}, open(d / "model_card.yaml", "w"))
+    last = create_model_card_from_training_folder(tmp_path / "run", "tmp_card")
+    assert last["checkpoint"].endswith("checkpoints/step_20/model.pt") and last["name"] == "tmp_card" and last["model_config"] == {"model_dim": 256}
+    assert create_model_card_from_training_folder(tmp_path / "run", "tmp_card", step_nr=10)["checkpoint"].endswith("step_10/model.pt")
+    (tmp_path / "run" / "checkpoints" / "step_30").mkdir()
+    with pytest.raises(ValueError, match="model_card.yaml"):
+        create_model_card_from_training_folder(tmp_path / "run", "tmp_card")
+    # DDP prefix
+    ck = {"model": {"module.a.weight": 1, "b": 2}}
+    assert convert_lcm_checkpoint(ck)["model"] == {"a.weight": 1, "b": 2}
+
+
 def test_option_defaults_match_reference():
     # lcm/inference/lcm/generator.py:29-58 and lcm/inference/two_tower_diffusion_lcm/generator.py:29-73
     from lcm.inference.two_tower_diffusion_lcm import DiffusionLCMGeneratorOptions
