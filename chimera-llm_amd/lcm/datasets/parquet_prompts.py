@@ -73,14 +73,27 @@ def get_embeddings_sequence(src_seqs: Sequence[Tensor], tgt_seqs: Optional[Seque
 
 def iterate_prompt_batches(path: str, column: str, batch_size: int, *, device="cuda", dtype=torch.float32,
                            split: Optional[str] = None, max_prompt_len: Optional[int] = None,
-                           max_documents: Optional[int] = None, rank: int = 0,
-                           world_size: int = 1) -> Iterator[EmbeddingsBatch]:
+                           max_documents: Optional[int] = None, rank: int = 0, world_size: int = 1,
+                           prefix_embeddings: Optional[Tensor] = None,
+                           suffix_embeddings: Optional[Tensor] = None) -> Iterator[EmbeddingsBatch]:
     """Padded prompt batches of this rank's documents, ready for `generator(batch)`.  Prompts longer than
-    `max_prompt_len` keep their first `max_prompt_len` sentences."""
+    `max_prompt_len` keep their first `max_prompt_len` sentences.  `prefix_embeddings` / `suffix_embeddings` (k, D):
+    sentence embeddings put before / after every prompt, the way the reference's loader wraps a source in its
+    `source_prefix_text` / `source_suffix_text` (lcm/datasets/dataloading.py:597-613); the reference encodes those
+    texts with SONAR itself, here the caller brings them already encoded.  The length cut applies to the document, not
+    to the affixes."""
     docs, _ = read_sonar_documents(path, column, split=split, max_documents=max_documents, rank=rank, world_size=world_size)
     if max_prompt_len is not None:
         docs = [d[:max_prompt_len] for d in docs]
     docs = [d for d in docs if d.shape[0] > 0]
+    for name, t in (("prefix_embeddings", prefix_embeddings), ("suffix_embeddings", suffix_embeddings)):
+        if t is not None and (t.dim() != 2 or (docs and t.shape[1] != docs[0].shape[1])):
+            raise ValueError(f"{name} must be (sentences, {docs[0].shape[1] if docs else 'D'}), got {tuple(t.shape)}")
+
+    def wrap(d: Tensor) -> Tensor:
+        parts = [t.to(d.dtype) for t in (prefix_embeddings, d, suffix_embeddings) if t is not None]
+        return d if len(parts) == 1 else torch.cat(parts)
+
     for i in range(0, len(docs), batch_size):
-        chunk = [d.to(device=device, dtype=dtype, non_blocking=True) for d in docs[i:i + batch_size]]
+        chunk = [wrap(d).to(device=device, dtype=dtype, non_blocking=True) for d in docs[i:i + batch_size]]
         yield get_embeddings_sequence(chunk)

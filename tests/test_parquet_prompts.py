@@ -60,3 +60,19 @@ def test_get_embeddings_sequence_with_targets():
     assert b.padding_mask.seq_lens.tolist() == [3, 5]
     d = get_embeddings_sequence(src, tgt, double_target=True)
     assert d.seqs.shape == (2, 7, 4) and d.padding_mask.seq_lens.tolist() == [4, 7]
+
+
+def test_prompt_affixes(tmp_path):
+    """Already-encoded prefix / suffix sentences around every prompt (the reference wraps sources in its
+    source_prefix_text / source_suffix_text, lcm/datasets/dataloading.py:597-613)."""
+    lens = [3, 1, 5]
+    docs = _write(tmp_path / "d.parquet", lens, True)
+    pre, suf = torch.full((2, 1024), 7.0), torch.full((1, 1024), -7.0)
+    (b,) = list(iterate_prompt_batches(str(tmp_path / "d.parquet"), "text_sentences_sonar_emb", 8, device="cpu",
+                                       max_prompt_len=4, prefix_embeddings=pre, suffix_embeddings=suf))
+    assert b.seqs.shape == (3, 7, 1024) and b.padding_mask.seq_lens.tolist() == [6, 4, 7]
+    assert torch.equal(b.seqs[1, :2], pre) and torch.equal(b.seqs[1, 2], torch.from_numpy(docs[1][0])) and torch.equal(b.seqs[1, 3:4], suf)
+    assert torch.equal(b.seqs[2, 2:6], torch.from_numpy(docs[2][:4])) and torch.equal(b.seqs[2, 6:7], suf)
+    with pytest.raises(ValueError, match="prefix_embeddings"):
+        list(iterate_prompt_batches(str(tmp_path / "d.parquet"), "text_sentences_sonar_emb", 8, device="cpu",
+                                    prefix_embeddings=torch.zeros(2, 512)))
