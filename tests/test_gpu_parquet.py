@@ -81,3 +81,50 @@ def test_parquet_prompts_through_the_generator(tmp_path, normalizer):
     sharded = dict(run(0, 2) + run(1, 2))
     assert sorted(sharded) == sorted(got)
     assert all(sharded[i].shape[0] == lens[i] + G for i in sharded)
+
+
+def test_generate_continuations_of_a_prompt_list(normalizer):
+    """`lcm.inference.predict.generate_continuations`, the embedding-level part of the reference's predictor
+    (lcm/evaluation/predictors/lcm.py:205-262): prompt cut, generator batches, padding, `max_gen_len_ratio`, results in
+    prompt order without their prompts -- against the oracle, document by document (device-drawn noise is replaced by
+    `noise=` per batch through the generator keyword, indexed by the batch's own documents)."""
+    from lcm.inference.predict import generate_continuations
+    from lcm.inference.two_tower_diffusion_lcm import DiffusionLCMGeneratorOptions, TwoTowerDiffusionLCMGenerator
+    from lcm.models.two_tower_diffusion_lcm import create_two_tower_diffusion_lcm_model
+    from oracle.weights import synthetic_prompts
+    cfg = O.get_arch("mini_two_tower_diffusion_lcm")
+    sd = O.init_state_dict(cfg, seed=4, mod_gain=10.0, qk_gain=2.0)
+    lens = [5, 2, 3, 4, 1]
+    full = synthetic_prompts(normalizer, len(lens), 6, seed=55)
+    prompts = [full[i, :n + 1] for i, n in enumerate(lens)]                 # one sentence more than will be kept
+    model = create_two_tower_diffusion_lcm_model(mini_config(), device="cuda:0", dtype=torch.float32)
+    model.load_state_dict(sd)
+    opts = dict(DEFAULT_OPTS, inference_timesteps=10, seed=9)
+    gen = TwoTowerDiffusionLCMGenerator(model, DiffusionLCMGeneratorOptions(**opts))
+    outs = generate_continuations(gen, [p.cuda() for p in prompts], max_gen_len_ratio=0.5, max_prompt_len=5, generator_batch_size=2)
+    kept = [min(n + 1, 5) for n in lens]
+    # batches of (2, 2, 1) documents; each generates max(1, int(longest kept prompt * 0.5)) sentences
+    want_len = [2, 2, 2, 2, 1]
+    assert [o.shape for o in outs] == [(g, 1024) for g in want_len]
+    # the same batches by hand, with the draws the seeded generator makes on the device, through the oracle
+    om = O.OracleTwoTower(cfg, sd)
+    for b0 in range(0, 5, 2):
+        idx = list(range(b0, min(b0 + 2, 5)))
+        G = want_len[b0]
+        pl = [kept[i] for i in idx]
+        x = torch.zeros(len(idx), max(pl), 1024)
+        for r, i in enumerate(idx):
+            x[r, :pl[r]] = prompts[i][:pl[r]]
+        torch.manual_seed(9)
+        steps = max(pl) - min(pl) + G
+        nz = torch.zeros(steps, len(idx), 1024)
+        for st in range(steps):          # one (active documents, 1, D) draw per step; a document leaves after its last sentence
+            active = [r for r in range(len(idx)) if st < pl[r] - min(pl) + G]
+            nz[st, active] = torch.randn(len(active), 1, 1024, device="cuda:0")[:, 0].cpu()
+        ref = O.OracleGenerator(om, O.GenOptions(**{k: v for k, v in opts.items() if k != "seed"}))(
+            x, prompt_lens=torch.tensor(pl), max_gen_len=G, noise=nz)
+        for r, i in enumerate(idx):
+            a, b = outs[i].cpu(), ref[r][0].seq[pl[r]:]
+            an, bn = (a - normalizer["center"]) / normalizer["scale"], (b - normalizer["center"]) / normalizer["scale"]
+            assert a.shape == b.shape and float((an - bn).abs().max()) <= FP32_MAX_ABS, (i, float((an - bn).abs().max()))
+    del model
