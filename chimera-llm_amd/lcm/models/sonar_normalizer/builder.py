@@ -3,8 +3,7 @@
 `normalize` / `denormalize` follow the reference's lcm/models/sonar_normalizer/builder.py:121-137
 (centre/scale, optional quantile clipping) and run in the coalesced `lcmhip_normalize` /
 `lcmhip_denormalize` kernels; the packed real FFT of the "*_fft" archs (`FFTInterface`, builder.py:58-84)
-runs in `lcmhip_rfft_pack`.  `fit` (:139-193, scikit-learn on the host) is not part of the generation
-path and raises.
+runs in `lcmhip_rfft_pack`.  `fit` (:139-193) is the reference's host-side scikit-learn pass.
 """
 
 from dataclasses import dataclass
@@ -93,8 +92,35 @@ class SonarNormalizer(FFTInterface):
             y = _hip.rfft_pack(y, inverse=True).to(y.dtype)
         return y
 
-    def fit(self, embeddings: Tensor):
-        raise NotImplementedError("fitting a normalizer is outside the generation path")
+    @torch.no_grad()
+    def fit(self, embeddings: Tensor) -> None:
+        """Fits center / scale (and the clipping quantiles) to `embeddings` (N, dim), as the reference does
+        (builder.py:139-193): scikit-learn's RobustScaler ("robust", "gaussian_robust": median and the spread between the
+        configured quantiles, which scikit-learn reads as PERCENT, so the defaults 0.25 / 0.75 are the 0.25th and 0.75th
+        percentile) or StandardScaler ("standard"), on the host in fp32; the clipping bounds are quantiles of the scaled
+        data.  A host-side, one-off statistics pass: no kernel of this library is involved except the packed FFT of the
+        "*_fft" archs, which needs the embeddings on the GPU."""
+        method = self.config.normalization_method
+        if method in ("robust", "gaussian_robust"):
+            from sklearn.preprocessing import RobustScaler
+            scaler = RobustScaler(unit_variance=method == "gaussian_robust",
+                                  quantile_range=(self.config.quantile_min, self.config.quantile_max))
+        elif method == "standard":
+            from sklearn.preprocessing import StandardScaler
+            scaler = StandardScaler()
+        else:
+            raise ValueError(f"Unrecognizable method {method} for scaling input features")
+        assert embeddings.dim() == 2 and embeddings.shape[-1] == self.config.dim
+        if self.config.with_fft:
+            embeddings = self.fft_transform(embeddings)
+        scaled = scaler.fit_transform(embeddings.cpu().float().numpy())
+        center = scaler.mean_ if method == "standard" else scaler.center_
+        self.center.copy_(torch.tensor(center, dtype=self.center.dtype))
+        self.scale.copy_(torch.tensor(scaler.scale_, dtype=self.scale.dtype))
+        if self.config.clip_proba is not None:
+            t = torch.tensor(scaled)
+            self.clip_min.copy_(torch.quantile(t, self.config.clip_proba, dim=0).to(self.clip_min.dtype))
+            self.clip_max.copy_(torch.quantile(t, 1 - self.config.clip_proba, dim=0).to(self.clip_max.dtype))
 
 
 def create_sonar_normalizer(config: SonarNormalizerConfig, *, device=None, dtype=None) -> SonarNormalizer:

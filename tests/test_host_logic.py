@@ -225,6 +225,36 @@ def test_card_utilities_and_model_type_registry(tmp_path):
     assert convert_lcm_checkpoint(ck)["model"] == {"a.weight": 1, "b": 2}
 
 
+@pytest.mark.parametrize("method", ["gaussian_robust", "robust", "standard"])
+def test_normalizer_fit_statistics(method):
+    """`SonarNormalizer.fit` (sonar_normalizer/builder.py:139-193) against the statistics written out by hand: median
+    and the spread between the 0.25th and 0.75th PERCENTILE (scikit-learn reads the configured quantiles as percent),
+    divided by the same spread of a unit normal for "gaussian_robust"; mean and population deviation for "standard";
+    clipping bounds = quantiles of the scaled data."""
+    import numpy as np
+    from scipy.stats import norm
+    from lcm.models.sonar_normalizer.builder import SonarNormalizer, SonarNormalizerConfig
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(4000, 16, generator=g) * torch.linspace(0.5, 3.0, 16) + torch.linspace(-2, 2, 16))
+    n = SonarNormalizer(SonarNormalizerConfig(dim=16, normalization_method=method, clip_proba=0.01))
+    n.fit(x)
+    xn = x.double().numpy()
+    if method == "standard":
+        center, scale = xn.mean(0), xn.std(0)
+    else:
+        center = np.median(xn, axis=0)
+        lo, hi = np.percentile(xn, (0.25, 0.75), axis=0)
+        scale = hi - lo
+        if method == "gaussian_robust":
+            scale = scale / (norm.ppf(0.0075) - norm.ppf(0.0025))
+    assert np.allclose(n.center.numpy(), center, rtol=1e-4, atol=1e-5) and np.allclose(n.scale.numpy(), scale, rtol=1e-4)
+    scaled = (xn - center) / scale
+    assert np.allclose(n.clip_min.numpy(), np.quantile(scaled, 0.01, axis=0), rtol=1e-3, atol=1e-3)
+    assert np.allclose(n.clip_max.numpy(), np.quantile(scaled, 0.99, axis=0), rtol=1e-3, atol=1e-3)
+    with pytest.raises(ValueError):
+        SonarNormalizer(SonarNormalizerConfig(dim=16, normalization_method="other")).fit(x)
+
+
 def test_option_defaults_match_reference():
     # lcm/inference/lcm/generator.py:29-58 and lcm/inference/two_tower_diffusion_lcm/generator.py:29-73
     from lcm.inference.two_tower_diffusion_lcm import DiffusionLCMGeneratorOptions
