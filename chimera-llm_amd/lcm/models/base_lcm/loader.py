@@ -19,6 +19,9 @@ def load_base_lcm_config(name_or_card) -> BaseLCModelConfig:
     return config
 
 
+load_base_lcm_config._arch_configs = lcm_archs      # where fairseq2's StandardModelConfigLoader keeps its arch registry
+
+
 def load_base_lcm_model(name_or_card, device=None, dtype=None) -> BaseLCModel:
     from lcm.models.sonar_normalizer.loader import load_sonar_normalizer_model
     from lcm.utils.card_utils import resolve_card, resolve_checkpoint_path

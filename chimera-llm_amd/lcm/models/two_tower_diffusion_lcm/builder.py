@@ -57,6 +57,14 @@ class _ArchRegistry(dict):
             raise KeyError(f"unknown two_tower_diffusion_lcm architecture '{name}' (known: {sorted(self)})")
         return self[name]()
 
+    # the calls of fairseq2's ConfigRegistry that the reference's code and tests use on `lcm_archs`
+    def get(self, name: str, *unused):  # type: ignore[override]
+        """A fresh configuration of the named architecture (not the registered factory, as dict.get would return)."""
+        return self.get_config(name)
+
+    def names(self):
+        return set(self.keys())
+
 
 lcm_archs = _ArchRegistry()
 lcm_arch = lcm_archs.decorator

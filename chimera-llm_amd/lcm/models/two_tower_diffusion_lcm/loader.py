@@ -38,6 +38,9 @@ def load_two_tower_diffusion_lcm_config(name_or_card) -> TwoTowerDiffusionLCMode
     return config
 
 
+load_two_tower_diffusion_lcm_config._arch_configs = lcm_archs      # where fairseq2's StandardModelConfigLoader keeps its arch registry
+
+
 def convert_lcm_checkpoint(checkpoint: Dict[str, Any], config: Any = None) -> Dict[str, Any]:
     """DDP checkpoints: the `module.` prefix of the state-dict keys is removed in place (base_lcm/loader.py:24-30)."""
     sd = checkpoint["model"]

@@ -355,3 +355,93 @@ def test_option_statements_against_golden_fixture():
     f = blob["fft"]
     assert (_hip.rfft_pack(f["x"].cuda(), inverse=False).cpu() - f["packed"]).abs().max() <= 5e-6 * f["packed"].abs().max()
     assert (_hip.rfft_pack(f["packed"].cuda(), inverse=True).cpu() - f["back"]).abs().max() <= 5e-6 * f["back"].abs().max()
+
+
+def _reference_style_generate(model, prompts, batch_size, max_gen_len, options, disable_cache=False):
+    """The loop of the reference's tests: prompts taken `batch_size` at a time, padded, generated; best hypotheses in
+    prompt order."""
+    from lcm.datasets.batch import EmbeddingsBatch, pad_seqs
+    from lcm.inference.lcm import LCMGenerator, LCMGeneratorOptions
+    gen = LCMGenerator(model, eos_vec=torch.zeros(prompts[0].shape[1], device="cuda:0"), options=LCMGeneratorOptions(**options))
+    outs = []
+    for i in range(0, len(prompts), batch_size):
+        padded = EmbeddingsBatch(*pad_seqs([p.cuda() for p in prompts[i:i + batch_size]]))
+        outs.extend(h[0].seq for h in gen(padded, max_gen_len=max_gen_len, disable_cache=disable_cache).hypotheses)
+    return outs
+
+
+@pytest.mark.parametrize("disable_cache,eos_threshold", [(True, 0.3), (True, 1.1), (False, 0.3), (False, 1.1)])
+def test_reference_caching_and_batching(disable_cache, eos_threshold):
+    """The reference's tests/units/inference/test_base_lcm_batched_inference.py:21-96 at a width these kernels take:
+    five prompts of random lengths generated three at a time and one at a time, with and without the KV cache, a zero
+    EOS vector under both of its thresholds, no sampling: the outputs agree to atol 1e-6."""
+    from lcm.models.base_lcm import create_base_lcm_model
+    from oracle.weights import synthetic_prompts
+    g = torch.Generator().manual_seed(17)
+    model = create_base_lcm_model(base_config("mini_base_lcm"), device="cuda:0", dtype=torch.float32, seed=3)
+    full = synthetic_prompts(oracle.load_dummy_normalizer(), 5, 7, seed=31)
+    prompts = [full[i, :int(torch.randint(1, 8, (1,), generator=g))] for i in range(5)]
+    opts = dict(eos_threshold=eos_threshold, sample_latent_variable=False)
+    batched = _reference_style_generate(model, prompts, 3, 8, opts, disable_cache)
+    single = _reference_style_generate(model, prompts, 1, 8, opts, disable_cache)
+    assert len(batched) == len(single) == 5
+    for a, b, p in zip(batched, single, prompts):
+        assert a.shape == b.shape and a.shape[0] == p.shape[0] + 8 and torch.isfinite(a).all()
+        assert torch.allclose(a, b, atol=1e-6), float((a - b).abs().max())
+
+
+@pytest.mark.parametrize("batch_size", [3, 1])
+def test_reference_single_input_stopping(batch_size):
+    """tests/units/inference/test_base_lcm_batched_inference.py:99-155: with an EOS criterion that never fires, no
+    document stops before `max_gen_len`, in a batch of three and alone."""
+    from lcm.models.base_lcm import create_base_lcm_model
+    from oracle.weights import synthetic_prompts
+    g = torch.Generator().manual_seed(batch_size)
+    model = create_base_lcm_model(base_config("mini_base_lcm"), device="cuda:0", dtype=torch.float32, seed=3)
+    full = synthetic_prompts(oracle.load_dummy_normalizer(), batch_size, 4, seed=32)
+    prompts = [full[i, :int(torch.randint(1, 5, (1,), generator=g))] for i in range(batch_size)]
+    outs = _reference_style_generate(model, prompts, 3, 3, dict(eos_threshold=1, sample_latent_variable=False, trim_hypotheses=False))
+    for o, p in zip(outs, prompts):
+        assert o.shape[0] - p.shape[0] == 3
+
+
+@pytest.mark.parametrize("prefix_len", [1, 2, 8])
+def test_reference_kv_caching(prefix_len):
+    """tests/units/inference/test_base_lcm_kv_caching.py:17-74 at a width these kernels take: one document of 1 / 2 / 8
+    prompt sentences (with one sentence the prefill is a no-op), 8 generated, stopping rules that never fire, no
+    sampling, a seed; without and with the KV cache the outputs agree to atol 1e-3."""
+    from lcm.datasets.batch import EmbeddingsBatch
+    from lcm.inference.lcm import LCMGenerator, LCMGeneratorOptions
+    from lcm.models.base_lcm import create_base_lcm_model
+    from oracle.weights import synthetic_prompts
+    model = create_base_lcm_model(base_config("mini_base_lcm"), device="cuda:0", dtype=torch.float32, seed=3)
+    x = synthetic_prompts(oracle.load_dummy_normalizer(), 1, prefix_len, seed=40 + prefix_len).cuda()
+    gen = LCMGenerator(model, eos_vec=torch.zeros(1024, device="cuda:0"),
+                       options=LCMGeneratorOptions(eos_threshold=1, stop_on_repetition_cosine_threshold=1,
+                                                   sample_latent_variable=False, seed=0))
+    no_cache = gen(EmbeddingsBatch(seqs=x, padding_mask=None), max_gen_len=8, disable_cache=True)
+    cached = gen(EmbeddingsBatch(seqs=x, padding_mask=None), max_gen_len=8, disable_cache=False)
+    a, b = no_cache.hypotheses[0][0].seq, cached.hypotheses[0][0].seq
+    assert a.shape == b.shape == (prefix_len + 8, 1024) and torch.isfinite(a).all()
+    assert torch.allclose(a, b, atol=1e-3), float((a - b).abs().max())
+
+
+def test_reference_next_sentence_prediction():
+    """tests/units/models/test_lcm_architecture.py:78-112, call for call: the toy architecture taken from the model-type
+    registry's config loader, built by its model factory; `predict_next_sentence` over all positions is deterministic
+    without sampling and random with it."""
+    from lcm.datasets.batch import EmbeddingsBatch
+    from lcm.models.base_lcm import BASE_LCM_MODEL_TYPE
+    from lcm.utils.model_type_registry import lcm_model_type_registry
+    model_type_cfg = lcm_model_type_registry.get_config(BASE_LCM_MODEL_TYPE)
+    model_cfg = model_type_cfg.config_loader._arch_configs.get(f"toy_{BASE_LCM_MODEL_TYPE}")
+    model = model_type_cfg.model_factory(model_cfg)
+    model.eval()
+    x = (torch.randn(size=[5, 17, 1024]) * 0.006).cuda()
+    batch = EmbeddingsBatch(x, padding_mask=None)
+    first = model.predict_next_sentence(batch, sample=False).seqs
+    assert first.shape == x.shape and torch.isfinite(first).all()
+    assert torch.allclose(first, model.predict_next_sentence(batch, sample=False).seqs)
+    random_prediction = model.predict_next_sentence(batch, sample=True, temperature=0.01).seqs
+    assert random_prediction.shape == x.shape
+    assert not torch.allclose(random_prediction, first)
