@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256, 4) void k_attention_prefill(const bf16_t* __re
 int launch_attention_q(const AttnQ& qa, const void* kc, const void* vc, const int32_t* slot_map, void* out, int n_docs,
                        int s, int n_heads, int cap, int base_keys, int causal, int dtype, hipStream_t st,
                        const int32_t* base_keys_dev, const KeyWindow* win) {
-    LCM_REQUIRE(n_heads % 4 == 0 || n_heads == 2, "attention: heads must be a multiple of 4 (or 2)");
+    LCM_REQUIRE(n_heads >= 1, "attention: needs at least one head");
     LCM_REQUIRE(n_docs >= 0 && s >= 1 && base_keys >= 0, "attention: bad shape");
     KeyWindow kw;
     if (win) kw = *win;
@@ -491,7 +491,7 @@ int launch_attention_q(const AttnQ& qa, const void* kc, const void* vc, const in
         LCM_HIP_CHECK(hipGetLastError());
         return LCMHIP_OK;
     }
-    const int waves = n_heads >= 4 ? 4 : n_heads;
+    const int waves = n_heads % 4 == 0 ? 4 : (n_heads % 2 == 0 ? 2 : 1);   // heads of one query row per workgroup, a wave each
     dim3 grid((unsigned)(n_docs * s * (n_heads / waves))), block(64 * waves);
     if (dtype == LCMHIP_BF16)
         hipLaunchKernelGGL((k_attention<bf16_t>), grid, block, 0, st, qa, (const bf16_t*)kc, (const bf16_t*)vc, slot_map,

@@ -199,7 +199,6 @@ static int get_ffn(lcmhip_model* m, const std::string& p, int d, const lcmhip_to
 static int check_tower(const lcmhip_tower_desc& t, int d, int dtype, const char* which) {
     LCM_REQUIRE(t.num_layers >= 1, std::string(which) + ": needs at least one layer");
     LCM_REQUIRE(t.num_heads >= 2 && d == t.num_heads * 128, std::string(which) + ": head_dim must be 128");
-    LCM_REQUIRE(t.num_heads % 4 == 0 || t.num_heads == 2, std::string(which) + ": heads must be 2 or a multiple of 4");
     // the down-projection streams K = ffn_dim operands in whole 512-byte chunks
     LCM_REQUIRE(t.ffn_dim % (dtype == LCMHIP_BF16 ? 256 : 128) == 0,
                 std::string(which) + ": ffn_dim must be a multiple of 128 (fp32) / 256 (bf16)");

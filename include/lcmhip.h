@@ -90,7 +90,7 @@ typedef struct lcmhip_session lcmhip_session;
 /* One transformer stack (contextualizer or denoiser); lcm/nn/transformer/factory.py:47-123. */
 typedef struct {
     int32_t num_layers;
-    int32_t num_heads;     /* model_dim / num_heads must be 128; 2 or a multiple of 4 heads */
+    int32_t num_heads;     /* model_dim / num_heads must be 128 (so the count is even) */
     int32_t ffn_dim;       /* inner width actually allocated (after GLU rounding); a multiple of 128 (fp32) / 256 (bf16) */
     int32_t norm_kind;     /* LCMHIP_NORM_* */
     int32_t ffn_kind;      /* LCMHIP_FFN_*  */
