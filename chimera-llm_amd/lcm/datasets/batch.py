@@ -6,7 +6,8 @@ PaddingMask that callers of this path read (`seq_lens`, `materialize()`).
 
 import copy
 from dataclasses import dataclass
-from typing import List, Optional
+from enum import Enum
+from typing import Any, Dict, List, Optional, Tuple, Union
 
 import torch
 from torch import Tensor
@@ -104,6 +105,22 @@ class EmbeddingsBatch:
             return list(self.seqs)
         return [row[: int(n)] for row, n in zip(self.seqs, self.padding_mask.seq_lens)]
 
+    def double_seqs(self) -> "EmbeddingsBatch":
+        """Every position twice in a row (1, 2, 3 -> 1, 1, 2, 2, 3, 3), lengths and source lengths with it (reference
+        batch.py:164-188); the diffusion timesteps and document lengths are carried over as they are."""
+        mask = self.padding_mask
+        return EmbeddingsBatch(
+            self.seqs.repeat_interleave(2, dim=1),
+            None if mask is None else PaddingMask(2 * mask.seq_lens, 2 * mask._batch_seq_len),
+            self.diffusion_timesteps, self.document_lengths,
+            None if self.source_lengths is None else self.source_lengths.repeat_interleave(2, dim=0))
+
+    def flatten_to_sentences(self) -> Tensor:
+        """(sum of lengths, D): the unpadded positions of all sequences, in batch order (reference batch.py:190-218)."""
+        if self.padding_mask is None:
+            return self.seqs.reshape(-1, self.seqs.size(-1))
+        return self.seqs[self.padding_mask.materialize().to(self.seqs.device)]
+
     def _with_seqs(self, seqs: Tensor) -> "EmbeddingsBatch":
         return EmbeddingsBatch(seqs, self.padding_mask, self.diffusion_timesteps, self.document_lengths,
                                self.source_lengths)
@@ -113,3 +130,90 @@ class EmbeddingsBatch:
 
     def denormalize_seqs(self, normalizer) -> "EmbeddingsBatch":
         return self if normalizer is None else self._with_seqs(normalizer.denormalize(self.seqs))
+
+
+class LCMStyle(Enum):
+    """How an `LCMInput` becomes model input (reference batch.py:28-40)."""
+    UNSUPERVISED = 0
+    SUPERVISED = 1
+    PACKED_UNSUPERVISED = 2
+
+
+DOC_LENGTHS = "__doc_lengths"       # the column of a raw loader batch that holds the lengths of packed documents
+
+
+def get_embeddings_sequence(src_seqs: List[Tensor], tgt_seqs: Optional[List[Tensor]] = None,
+                            document_lengths: Optional[Tensor] = None, double_target: bool = False) -> EmbeddingsBatch:
+    """Source (followed by target, optionally with every target position twice) per document, right-padded into one
+    batch; `source_lengths` is filled in when there are targets (reference batch.py:381-425)."""
+    rows = []
+    for i, src in enumerate(src_seqs):
+        if tgt_seqs is None or tgt_seqs[i] is None:
+            rows.append(src)
+            continue
+        tgt = tgt_seqs[i].to(device=src.device, dtype=src.dtype)
+        rows.append(torch.cat([src, tgt.repeat_interleave(2, dim=0) if double_target else tgt]))
+    seqs, mask = pad_seqs(rows)
+    return EmbeddingsBatch(
+        seqs, mask,
+        document_lengths=None if document_lengths is None else document_lengths.to(seqs.device),
+        source_lengths=None if tgt_seqs is None else torch.tensor([s.size(0) for s in src_seqs], device=seqs.device))
+
+
+@dataclass
+class LCMInput:
+    """Source / target documents of SONAR embeddings as the loaders hand them over (reference batch.py:221-378)."""
+    source: List[Tensor]
+    target: Optional[List[Tensor]] = None
+    tokens: Any = None
+    target_tokens: Any = None
+    name: Optional[str] = None
+    batch: Optional[Dict[str, Any]] = None
+
+    def __post_init__(self) -> None:
+        assert self.source is not None
+        assert self.target is None or len(self.target) == len(self.source), (
+            f"all elements in LCMInput should be of the same length, got {len(self.target)} and {len(self.source)}")
+
+    def __len__(self) -> int:
+        return len(self.source)
+
+    def __getitem__(self, i: int) -> Union[Tensor, Tuple[Tensor, Tensor]]:
+        return self.source[i] if self.target is None else (self.source[i], self.target[i])
+
+    def prepare_input(self, style: LCMStyle = LCMStyle.UNSUPERVISED) -> EmbeddingsBatch:
+        if style == LCMStyle.UNSUPERVISED:
+            return get_embeddings_sequence(self.source)
+        if style == LCMStyle.PACKED_UNSUPERVISED:
+            lengths = None if self.batch is None else self.batch.get(DOC_LENGTHS)
+            if lengths is not None:
+                assert len(lengths) == 1, "Expecting batch size of 1"       # packed documents come one row at a time
+                lengths = lengths[0].type(torch.int64)
+            return get_embeddings_sequence(self.source, document_lengths=lengths)
+        if style == LCMStyle.SUPERVISED:
+            assert self.target is not None, "Missing target embeddings for a supervised batch"
+            return get_embeddings_sequence(self.source, self.target)
+        raise ValueError(f"Unsupported style={style} - could not prepare input")
+
+    def prepare_target_mask(self, embeddings: EmbeddingsBatch, style: LCMStyle,
+                            min_context_size: Optional[int] = None) -> Tensor:
+        """(B, S) bool: the positions a scorer or criterion judges.  Unsupervised: everything from `min_context_size`
+        on (per packed document when the batch carries document lengths); supervised: everything after the source;
+        padding is never a target."""
+        n, width, _ = embeddings.seqs.shape
+        device = embeddings.seqs.device
+        if style == LCMStyle.SUPERVISED:
+            src = torch.tensor([s.size(0) for s in self.source], device=device)
+            mask = torch.arange(width, device=device).unsqueeze(0) >= src.unsqueeze(1)
+        elif style == LCMStyle.PACKED_UNSUPERVISED and embeddings.document_lengths is not None:
+            start = torch.cat([torch.arange(int(m), device=device) for m in embeddings.document_lengths])
+            mask = (start >= (min_context_size or 0)).unsqueeze(0)
+        elif style in (LCMStyle.UNSUPERVISED, LCMStyle.PACKED_UNSUPERVISED):
+            mask = torch.ones(n, width, dtype=torch.bool, device=device)
+            if min_context_size is not None:
+                mask[:, :min_context_size] = False
+        else:
+            raise ValueError(f"Unsupported style={style}")
+        if embeddings.padding_mask is not None:
+            mask = mask & embeddings.padding_mask.materialize().to(device)
+        return mask

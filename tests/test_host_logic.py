@@ -484,3 +484,73 @@ def test_sinusoidal_table_equals_the_oracle_statement():
     assert torch.equal(got, sinusoidal_positions(0, 40, 256))
     assert torch.all(got[0, :128] == 0) and torch.all(got[0, 128:] == 1)
     assert sinusoidal_table(8, 256, device="cpu", dtype=torch.bfloat16).dtype == torch.bfloat16
+
+
+def test_reference_unbatch_and_last_element_of_ragged_batches():
+    """The reference's two container tests (tests/units/training/test_batch.py:14-40), call for call: pad -> unbatch ->
+    pad is the identity on 100 ragged sequences (empty ones among them), and `get_last_element` finds every sequence's
+    last unpadded row."""
+    from lcm.datasets.batch import EmbeddingsBatch, pad_seqs
+    torch.manual_seed(0)
+    ragged_seq = [torch.randn((i**2 % 11, 3)) for i in range(100)]
+    full_eb = EmbeddingsBatch(*pad_seqs(ragged_seq))
+    full_eb_bis = EmbeddingsBatch(*pad_seqs(full_eb.unbatch()))
+    assert (full_eb_bis.seqs == full_eb.seqs).all().item()
+    assert (full_eb_bis.padding_mask.seq_lens == full_eb.padding_mask.seq_lens).all().item()
+    assert full_eb_bis.padding_mask._batch_seq_len == full_eb.padding_mask._batch_seq_len
+
+    ragged_seq = [torch.randn((i**2 % 11 + 1, 3)) for i in range(100)]
+    full_eb = EmbeddingsBatch(*pad_seqs(ragged_seq))
+    expected_ans = torch.stack([tt[-1] for tt in ragged_seq], dim=0)
+    assert (expected_ans == full_eb.get_last_element()).all().item()
+
+
+def test_lcm_input_styles_and_target_masks():
+    """`LCMInput.prepare_input` / `prepare_target_mask` in the three styles, `double_seqs` and `flatten_to_sentences`
+    (reference lcm/datasets/batch.py:164-218, 268-425), against masks and layouts written out by hand."""
+    from lcm.datasets.batch import DOC_LENGTHS, EmbeddingsBatch, LCMInput, LCMStyle, get_embeddings_sequence
+    torch.manual_seed(1)
+    src = [torch.randn(3, 4), torch.randn(1, 4)]
+    tgt = [torch.randn(2, 4), torch.randn(2, 4, dtype=torch.float64)]
+    inp = LCMInput(source=src, target=tgt)
+    assert len(inp) == 2 and inp[1][0] is src[1] and inp[1][1] is tgt[1]
+    with pytest.raises(AssertionError, match="same length"):
+        LCMInput(source=src, target=tgt[:1])
+
+    sup = inp.prepare_input(LCMStyle.SUPERVISED)
+    assert tuple(sup.seqs.shape) == (2, 5, 4) and sup.seqs.dtype == torch.float32
+    assert sup.source_lengths.tolist() == [3, 1] and sup.padding_mask.seq_lens.tolist() == [5, 3]
+    assert torch.equal(sup.seqs[0], torch.cat([src[0], tgt[0]]))
+    assert torch.equal(sup.seqs[1, :3], torch.cat([src[1], tgt[1].float()])) and not sup.seqs[1, 3:].any()
+    assert inp.prepare_target_mask(sup, LCMStyle.SUPERVISED).tolist() == [
+        [False, False, False, True, True], [False, True, True, False, False]]
+
+    uns = inp.prepare_input()
+    assert tuple(uns.seqs.shape) == (2, 3, 4) and uns.source_lengths is None
+    assert inp.prepare_target_mask(uns, LCMStyle.UNSUPERVISED, min_context_size=1).tolist() == [
+        [False, True, True], [False, False, False]]
+    assert inp.prepare_target_mask(uns, LCMStyle.UNSUPERVISED).tolist() == [[True] * 3, [True, False, False]]
+    assert inp.prepare_target_mask(uns, LCMStyle.PACKED_UNSUPERVISED, min_context_size=7).tolist() == [[False] * 3] * 2
+
+    packed = LCMInput(source=[torch.randn(6, 4)], batch={DOC_LENGTHS: [torch.tensor([2, 1, 3], dtype=torch.int32)]})
+    pk = packed.prepare_input(LCMStyle.PACKED_UNSUPERVISED)
+    assert pk.document_lengths.dtype == torch.int64 and pk.document_lengths.tolist() == [2, 1, 3]
+    assert packed.prepare_target_mask(pk, LCMStyle.PACKED_UNSUPERVISED, min_context_size=1).tolist() == [
+        [False, True, False, False, True, True]]
+    with pytest.raises(AssertionError):                   # lengths that do not fill the row are refused by the container
+        LCMInput(source=[torch.randn(5, 4)], batch={DOC_LENGTHS: [torch.tensor([2, 1, 3])]}).prepare_input(
+            LCMStyle.PACKED_UNSUPERVISED)
+
+    dbl = get_embeddings_sequence(src, tgt, double_target=True)
+    assert dbl.padding_mask.seq_lens.tolist() == [7, 5]
+    assert torch.equal(dbl.seqs[0, 3:], tgt[0].repeat_interleave(2, dim=0))
+
+    two = sup.double_seqs()
+    assert tuple(two.seqs.shape) == (2, 10, 4) and two.padding_mask.seq_lens.tolist() == [10, 6]
+    assert two.padding_mask._batch_seq_len == 10 and two.source_lengths.tolist() == [3, 3, 1, 1]
+    assert torch.equal(two.seqs[:, 0::2], sup.seqs) and torch.equal(two.seqs[:, 1::2], sup.seqs)
+    assert EmbeddingsBatch(src[0][None]).double_seqs().padding_mask is None
+
+    flat = sup.flatten_to_sentences()
+    assert torch.equal(flat, torch.cat([src[0], tgt[0], src[1], tgt[1].float()]))
+    assert torch.equal(EmbeddingsBatch(src[0][None]).flatten_to_sentences(), src[0])
