@@ -111,3 +111,86 @@ def test_unknown_session_flags_are_rejected(hip):
     n = C.c_size_t(0)
     assert hip.lib.lcmhip_session_workspace_bytes(handle, 4, 16, 10, 1 << 9, C.byref(n)) == -1
     assert b"flag" in hip.lib.lcmhip_last_error()
+
+
+def _header_text():
+    import re
+    text = open(os.path.join(ROOT, "include", "lcmhip.h")).read()
+    return re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+
+
+def test_header_is_plain_c_and_the_binding_mirrors_its_layouts(tmp_path, hip):
+    """The header compiles as strict C99 on its own, and every struct the ctypes binding mirrors has the header's
+    size and field offsets; every constant the binding restates has the header's value.  A field added on one side
+    only, or reordered, fails here and not as garbage read by the library."""
+    import ctypes as C
+    import subprocess
+    structs = {"lcmhip_tower_desc": hip.TowerDesc, "lcmhip_model_desc": hip.ModelDesc,
+               "lcmhip_denoise_params": hip.DenoiseParams, "lcmhip_profile_row": hip.ProfileRow}
+    constants = {"LCMHIP_ABI_VERSION": hip.ABI_VERSION, "LCMHIP_STATIC_SCRATCH_BYTES": hip.STATIC_SCRATCH_BYTES,
+                 "LCMHIP_F32": hip.F32, "LCMHIP_BF16": hip.BF16,
+                 "LCMHIP_NORM_LAYERNORM": hip.NORM_LAYERNORM, "LCMHIP_NORM_RMS": hip.NORM_RMS,
+                 "LCMHIP_NORM_FP32": hip.NORM_FP32, "LCMHIP_NORM_UNIT": hip.NORM_UNIT,
+                 "LCMHIP_FFN_RELU": hip.FFN_RELU, "LCMHIP_FFN_SWIGLU": hip.FFN_SWIGLU,
+                 "LCMHIP_POS_NONE": hip.POS_NONE, "LCMHIP_POS_LEARNED": hip.POS_LEARNED, "LCMHIP_POS_ROPE": hip.POS_ROPE,
+                 "LCMHIP_POS_SINE": hip.POS_SINE, "LCMHIP_ORDER_PRE": hip.ORDER["pre"], "LCMHIP_ORDER_POST": hip.ORDER["post"],
+                 "LCMHIP_ORDER_NORMFORMER": hip.ORDER["normformer"], "LCMHIP_PRED_SAMPLE": hip.PRED["sample"],
+                 "LCMHIP_PRED_EPSILON": hip.PRED["epsilon"], "LCMHIP_PRED_V": hip.PRED["v_prediction"],
+                 "LCMHIP_EPI_STORE": hip.EPI_STORE, "LCMHIP_EPI_STORE_F32": hip.EPI_STORE_F32, "LCMHIP_EPI_RELU": hip.EPI_RELU,
+                 "LCMHIP_EPI_SWIGLU": hip.EPI_SWIGLU, "LCMHIP_EPI_RESID": hip.EPI_RESID,
+                 "LCMHIP_SESSION_KEEP_CONTEXT": hip.SESSION_KEEP_CONTEXT, "LCMHIP_SESSION_SEPARATE_QKV": hip.SESSION_SEPARATE_QKV,
+                 "LCMHIP_SESSION_SEPARATE_ROPE": hip.SESSION_SEPARATE_ROPE, "LCMHIP_SESSION_NO_GRAPH": hip.SESSION_NO_GRAPH}
+    constants.update({f"LCMHIP_ACT_{name.upper()}": code for name, code in hip.ACT.items()})
+    lines = ['#include "lcmhip.h"', "#include <stdio.h>", "int main(void) {"]
+    for cname, ct in structs.items():
+        lines.append(f'    printf("{cname} %zu\\n", sizeof({cname}));')
+        for field, _ in ct._fields_:
+            lines.append(f'    printf("{cname}.{field} %zu %zu\\n", offsetof({cname}, {field}), '
+                         f'sizeof((({cname}*)0)->{field}));')
+    for name in constants:
+        lines.append(f'    printf("{name} %ld\\n", (long)({name}));')
+    lines += ["    return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines) + "\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    str(src), "-o", str(exe)], check=True, capture_output=True)
+    seen = dict(line.split(" ", 1) for line in subprocess.run([str(exe)], check=True, capture_output=True,
+                                                               text=True).stdout.splitlines())
+    for cname, ct in structs.items():
+        assert int(seen[cname]) == C.sizeof(ct), (cname, seen[cname], C.sizeof(ct))
+        for field, _ in ct._fields_:
+            off, size = map(int, seen[f"{cname}.{field}"].split())
+            desc = getattr(ct, field)
+            assert (off, size) == (desc.offset, desc.size), (cname, field, off, size, desc.offset, desc.size)
+    for name, value in constants.items():
+        assert int(seen[name]) == value, (name, seen[name], value)
+
+
+def test_binding_signatures_follow_the_header(hip):
+    """Every prototype of the header is bound with the same number of arguments and the same kind of each (pointer,
+    32 / 64-bit integer, size, float), and returns what the header says."""
+    import ctypes as C
+    import re
+    protos = re.findall(r"(const char\s*\*|int)\s+(lcmhip_\w+)\s*\(([^)]*)\)\s*;", _header_text())
+    assert sorted(name for _, name, _ in protos) == sorted(hip.EXPORTS)
+
+    def kind_of_c(param):
+        param = " ".join(param.split())
+        if "*" in param:
+            return "pointer"
+        words = param.split()[:-1]                           # the type, without the parameter's name
+        base = [w for w in words if w != "const"]
+        return {"int32_t": "i32", "int": "i32", "uint32_t": "u32", "int64_t": "i64", "size_t": "size", "float": "f32"}[" ".join(base)]
+
+    def kind_of_ctypes(t):
+        if t in (C.c_void_p, C.c_char_p) or isinstance(t, type(C.POINTER(C.c_int))):
+            return "pointer"
+        return {C.c_int32: "i32", C.c_uint32: "u32", C.c_int64: "i64", C.c_size_t: "size", C.c_float: "f32"}[t]
+
+    for ret, name, params in protos:
+        fn = getattr(hip.lib, name)
+        want = [] if params.strip() in ("", "void") else [kind_of_c(p) for p in params.split(",")]
+        got = [kind_of_ctypes(t) for t in fn.argtypes]
+        assert got == want, (name, got, want)
+        assert fn.restype is (C.c_char_p if "char" in ret else C.c_int), (name, fn.restype)
