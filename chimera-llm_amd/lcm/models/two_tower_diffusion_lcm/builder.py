@@ -621,12 +621,21 @@ class TwoTowerDiffusionLCModel(AbstractLCModel):
     def num_parameters(self) -> int:
         return sum(t.numel() for n, t in self._params.items() if not n.startswith("sonar_normalizer."))
 
-    def _bind(self) -> None:
+    def model_desc(self) -> "_hip.ModelDesc":
+        """The lcmhip_model_desc this model was created from."""
         c = self.config
-
-        desc = _hip.ModelDesc(sonar_dim=c.sonar_embed_dim, model_dim=c.model_dim, max_seq_len=c.max_seq_len,
+        return _hip.ModelDesc(sonar_dim=c.sonar_embed_dim, model_dim=c.model_dim, max_seq_len=c.max_seq_len,
                               timestep_freq_dim=TIMESTEP_FREQ_DIM, dtype=_hip.dtype_code(self.dtype), norm_eps=1e-5,
                               context=tower_desc(c.context_encoder), denoiser=tower_desc(c.denoiser, denoiser=True))
+
+    def bound_tensors(self) -> Dict[str, Tensor]:
+        """Every tensor bound into the library's weight table, by name: the state dict plus the folded self-attention
+        products derived from it."""
+        self._ensure_folded()
+        return {**self._params, **self._derived}
+
+    def _bind(self) -> None:
+        desc = self.model_desc()
         _hip.check(_hip.lib.lcmhip_model_create(C.byref(desc), C.byref(self._handle)))
         code = _hip.dtype_code(self.dtype)
         for name, t in list(self._params.items()) + list(self._derived.items()):
