@@ -554,3 +554,31 @@ def test_lcm_input_styles_and_target_masks():
     flat = sup.flatten_to_sentences()
     assert torch.equal(flat, torch.cat([src[0], tgt[0], src[1], tgt[1].float()]))
     assert torch.equal(EmbeddingsBatch(src[0][None]).flatten_to_sentences(), src[0])
+
+
+def test_predictor_configs_are_the_generator_option_sets():
+    """`LCMConfig` / `TwoTowerDiffusionLCMConfig` (reference lcm/evaluation/predictors/lcm.py:33-56,
+    two_tower_diffusion_lcm.py:18-22): the generator's options plus the card and SONAR pipeline names, hashable, each
+    naming its predictor class; the dtype helper serves the reference's float16 default in bfloat16."""
+    import dataclasses
+    from lcm.datasets.configs import SonarDecoderConfig, SonarEncoderConfig
+    from lcm.evaluation.api import EOSConfig, Prediction
+    from lcm.evaluation.predictors import (LCMConfig, LCMPredictor, TwoTowerDiffusionLCMConfig,
+                                           TwoTowerDiffusionLCMPredictor, get_config_cls)
+    from lcm.evaluation.predictors.lcm import torch_type
+    from lcm.inference.lcm import LCMGeneratorOptions
+    from lcm.inference.two_tower_diffusion_lcm import DiffusionLCMGeneratorOptions
+    base = {f.name for f in dataclasses.fields(LCMConfig)}
+    assert {f.name for f in dataclasses.fields(LCMGeneratorOptions)} < base
+    assert {"model_card", "decoder_config", "encoder_config", "generator_batch_size"} <= base
+    two = {f.name for f in dataclasses.fields(TwoTowerDiffusionLCMConfig)}
+    assert base < two and {f.name for f in dataclasses.fields(DiffusionLCMGeneratorOptions)} <= two
+    c = TwoTowerDiffusionLCMConfig(model_card="m", guidance_scale=2.0)
+    assert isinstance(c, DiffusionLCMGeneratorOptions) and isinstance(c, LCMConfig) and isinstance(hash(c), int)
+    assert c.decoder_config == SonarDecoderConfig() and c.encoder_config == SonarEncoderConfig(lang="eng_Latn")
+    assert c.decoder_config.max_tokens_in_sentence == 256 and c.generator_batch_size is None
+    assert LCMConfig.predictor_class() is LCMPredictor and c.predictor_class() is TwoTowerDiffusionLCMPredictor
+    assert get_config_cls("two_tower_diffusion_lcm") is TwoTowerDiffusionLCMConfig
+    assert torch_type("torch.float32") is torch.float32 and torch_type("bfloat16") is torch.bfloat16
+    assert torch_type(None) is torch.bfloat16 and torch_type("torch.float16") is torch.bfloat16
+    assert Prediction(text=["a"]).embed is None and EOSConfig().text is None
