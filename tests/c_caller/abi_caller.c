@@ -2,7 +2,9 @@
  * tests/test_gpu_c_caller.py, builds the model from the tensors in it, runs
  *   reset -> context_append(prompt) -> denoise -> context_append(that sentence) -> denoise
  * and writes the two generated sentences to the output file.  The test compares them bit for bit with what the Python
- * host gets from the same library calls.
+ * host gets from the same library calls.  With a thread count as third argument that many workers run the flow at the
+ * same time, three times each, every worker with a session and a stream of its own on the one model; all must produce
+ * the same bits.
  *
  * Case file (little endian, no padding):
  *   int32 magic 0x4c434d31
@@ -17,6 +19,7 @@
  */
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -66,9 +69,71 @@ static void* to_device(const void* host, size_t n) {
     return d;
 }
 
+#define MAX_THREADS 16
+
+/* One worker's share: reset -> prefill -> sampling loop -> append -> sampling loop, `repeats` times on a fresh session
+ * each (so sessions and their recorded graphs are created and destroyed while other workers run theirs).  Copies go
+ * through the worker's own stream: the legacy stream's copies are refused while another thread records a graph. */
+struct flow {
+    lcmhip_model* model;
+    const lcmhip_denoise_params* params;
+    const int32_t* timesteps;
+    const float* alphas;
+    int32_t n_steps, n_train, step_ratio, n_docs, prompt_len, max_ctx, repeats;
+    float final_alpha;
+    size_t D;
+    const float* d_prompts;
+    const float* d_noise;
+    float* out;         /* host, 2 * n_docs * D */
+};
+
+static void* run_flow(void* arg) {
+    struct flow* w = (struct flow*)arg;
+    const size_t row = (size_t)w->n_docs * w->D;
+    HIP_OK(hipSetDevice(0));
+    hipStream_t stream;
+    HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    float* d_out = NULL;
+    HIP_OK(hipMalloc((void**)&d_out, 2 * row * sizeof(float)));
+    size_t ws_bytes = 0;
+    LCM_OK(lcmhip_session_workspace_bytes(w->model, w->n_docs, w->max_ctx, w->n_steps, 0u, &ws_bytes));
+    void* workspace = NULL;
+    HIP_OK(hipMalloc(&workspace, ws_bytes));           /* hipMalloc returns memory aligned well beyond 256 bytes */
+    for (int r = 0; r < w->repeats; ++r) {
+        lcmhip_session* session = NULL;
+        LCM_OK(lcmhip_session_create(w->model, w->n_docs, w->max_ctx, w->n_steps, 0u, workspace, ws_bytes, &session));
+        LCM_OK(lcmhip_session_set_schedule(session, w->timesteps, w->n_steps, w->alphas, w->n_train, w->final_alpha,
+                                           w->step_ratio, w->params, stream));
+        LCM_OK(lcmhip_session_reset(session, w->n_docs, stream));
+        LCM_OK(lcmhip_context_append(session, w->d_prompts, w->prompt_len, 0, stream));
+        LCM_OK(lcmhip_denoise(session, w->d_noise, d_out, NULL, stream));
+        /* the generated sentence becomes the next context position (n_docs, 1, sonar_dim) */
+        LCM_OK(lcmhip_context_append(session, d_out, 1, 0, stream));
+        LCM_OK(lcmhip_denoise(session, w->d_noise + row, d_out + row, NULL, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        if (lcmhip_session_context_len(session) != w->prompt_len + 1 || lcmhip_session_num_active(session) != w->n_docs) {
+            fprintf(stderr, "session reports context %d, %d active\n", lcmhip_session_context_len(session),
+                    lcmhip_session_num_active(session));
+            exit(5);
+        }
+        LCM_OK(lcmhip_session_destroy(session));       /* drains the stream its graphs last ran on */
+    }
+    HIP_OK(hipMemcpyAsync(w->out, d_out, 2 * row * sizeof(float), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    HIP_OK(hipFree(workspace));
+    HIP_OK(hipFree(d_out));
+    HIP_OK(hipStreamDestroy(stream));
+    return NULL;
+}
+
 int main(int argc, char** argv) {
-    if (argc != 3) {
-        fprintf(stderr, "usage: %s <case file> <output file>\n", argv[0]);
+    if (argc != 3 && argc != 4) {
+        fprintf(stderr, "usage: %s <case file> <output file> [threads]\n", argv[0]);
+        return 2;
+    }
+    const int n_threads = argc == 4 ? atoi(argv[3]) : 1;
+    if (n_threads < 1 || n_threads > MAX_THREADS) {
+        fprintf(stderr, "1 to %d threads\n", MAX_THREADS);
         return 2;
     }
     if (lcmhip_version() != LCMHIP_ABI_VERSION) {
@@ -115,8 +180,6 @@ int main(int argc, char** argv) {
     read_exact(f, noise, 2 * row_bytes);
 
     HIP_OK(hipSetDevice(0));
-    hipStream_t stream;
-    HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
 
     lcmhip_model* model = NULL;
     LCM_OK(lcmhip_model_create(&desc, &model));
@@ -146,55 +209,52 @@ int main(int argc, char** argv) {
     fclose(f);
     LCM_OK(lcmhip_model_finalize(model));
 
-    size_t ws_bytes = 0;
-    LCM_OK(lcmhip_session_workspace_bytes(model, n_docs, max_ctx, n_steps, 0u, &ws_bytes));
-    void* workspace = NULL;
-    HIP_OK(hipMalloc(&workspace, ws_bytes));           /* hipMalloc returns memory aligned well beyond 256 bytes */
-    lcmhip_session* session = NULL;
-    LCM_OK(lcmhip_session_create(model, n_docs, max_ctx, n_steps, 0u, workspace, ws_bytes, &session));
-    LCM_OK(lcmhip_session_set_schedule(session, timesteps, n_steps, alphas, n_train, final_alpha, step_ratio, &params,
-                                       stream));
-
     float* d_prompts = (float*)to_device(prompts, prompt_bytes);
     float* d_noise = (float*)to_device(noise, 2 * row_bytes);
-    float* d_out = NULL;
-    HIP_OK(hipMalloc((void**)&d_out, 2 * row_bytes));
 
-    LCM_OK(lcmhip_session_reset(session, n_docs, stream));
-    LCM_OK(lcmhip_context_append(session, d_prompts, prompt_len, 0, stream));
-    LCM_OK(lcmhip_denoise(session, d_noise, d_out, NULL, stream));
-    /* the generated sentence becomes the next context position (n_docs, 1, sonar_dim) */
-    LCM_OK(lcmhip_context_append(session, d_out, 1, 0, stream));
-    LCM_OK(lcmhip_denoise(session, d_noise + (size_t)n_docs * D, d_out + (size_t)n_docs * D, NULL, stream));
-    HIP_OK(hipStreamSynchronize(stream));
-    if (lcmhip_session_context_len(session) != prompt_len + 1 || lcmhip_session_num_active(session) != n_docs) {
-        fprintf(stderr, "session reports context %d, %d active\n", lcmhip_session_context_len(session),
-                lcmhip_session_num_active(session));
-        return 5;
+    /* every worker: a session, a stream and an output of its own on the shared model and inputs */
+    struct flow flows[MAX_THREADS];
+    pthread_t threads[MAX_THREADS];
+    for (int t = 0; t < n_threads; ++t) {
+        struct flow* w = &flows[t];
+        w->model = model; w->params = &params; w->timesteps = timesteps; w->n_steps = n_steps; w->alphas = alphas;
+        w->n_train = n_train; w->final_alpha = final_alpha; w->step_ratio = step_ratio; w->n_docs = n_docs;
+        w->prompt_len = prompt_len; w->max_ctx = max_ctx; w->D = D; w->d_prompts = d_prompts; w->d_noise = d_noise;
+        w->repeats = n_threads > 1 ? 3 : 1;
+        w->out = (float*)xmalloc(2 * row_bytes);
     }
-
-    float* out = (float*)xmalloc(2 * row_bytes);
-    HIP_OK(hipMemcpy(out, d_out, 2 * row_bytes, hipMemcpyDeviceToHost));
+    if (n_threads == 1) {
+        run_flow(&flows[0]);
+    } else {
+        for (int t = 0; t < n_threads; ++t)
+            if (pthread_create(&threads[t], NULL, run_flow, &flows[t]) != 0) {
+                fprintf(stderr, "pthread_create failed\n");
+                return 2;
+            }
+        for (int t = 0; t < n_threads; ++t) pthread_join(threads[t], NULL);
+    }
+    for (int t = 1; t < n_threads; ++t)
+        if (memcmp(flows[t].out, flows[0].out, 2 * row_bytes) != 0) {
+            fprintf(stderr, "thread %d produced other bits than thread 0\n", t);
+            return 6;
+        }
     FILE* g = fopen(argv[2], "wb");
-    if (!g || fwrite(out, 1, 2 * row_bytes, g) != 2 * row_bytes || fclose(g) != 0) {
+    if (!g || fwrite(flows[0].out, 1, 2 * row_bytes, g) != 2 * row_bytes || fclose(g) != 0) {
         perror(argv[2]);
         return 2;
     }
 
-    LCM_OK(lcmhip_session_destroy(session));
     LCM_OK(lcmhip_model_destroy(model));
-    HIP_OK(hipFree(workspace));
     HIP_OK(hipFree(d_prompts));
     HIP_OK(hipFree(d_noise));
-    HIP_OK(hipFree(d_out));
     for (int32_t i = 0; i < n_tensors; ++i) HIP_OK(hipFree(tensors[i]));
-    HIP_OK(hipStreamDestroy(stream));
+    for (int t = 0; t < n_threads; ++t) free(flows[t].out);
     free(tensors);
-    free(out);
     free(noise);
     free(prompts);
     free(alphas);
     free(timesteps);
-    printf("ok %d docs, context %d, %d steps\n", n_docs, prompt_len + 1, n_steps);
+    printf("ok %d docs, context %d, %d steps, %d thread%s\n", n_docs, prompt_len + 1, n_steps, n_threads,
+           n_threads == 1 ? "" : "s");
     return 0;
 }

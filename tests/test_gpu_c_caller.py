@@ -94,3 +94,12 @@ def test_c_caller_without_python_gets_the_same_bits(tmp_path, dtype):
     assert run.stdout.startswith("ok 5 docs, context 8"), run.stdout
     got = torch.frombuffer(bytearray(out.read_bytes()), dtype=torch.float32).reshape(2, n_docs, 1024)
     assert torch.equal(got, want), float((got - want).abs().max())
+
+    # four host threads of the C process at once, each with a session and a stream of its own on the one model, three
+    # sessions in a row per thread: the caller itself requires equal bits from every thread
+    out4 = tmp_path / "out4.bin"
+    run = subprocess.run([CALLER, str(case), str(out4), "4"], capture_output=True, text=True, timeout=240)
+    assert run.returncode == 0, (run.returncode, run.stdout[-2000:], run.stderr[-2000:])
+    assert run.stdout.startswith("ok 5 docs, context 8") and "4 threads" in run.stdout, run.stdout
+    got = torch.frombuffer(bytearray(out4.read_bytes()), dtype=torch.float32).reshape(2, n_docs, 1024)
+    assert torch.equal(got, want), float((got - want).abs().max())
