@@ -199,6 +199,52 @@ class DDIMScheduler:
                                                  rows, dim, a_t, a_prev, p, _hip.ptr(vn), _hip.stream_ptr(x.device)))
         return DDIMSchedulerOutput(prev, x0)
 
+    def _rows_by_timestep(self, first: Tensor, second: Tensor, timesteps: Tensor, alpha_t_of, alpha_prev_of,
+                          prediction_type: str, want_x0: bool) -> Tensor:
+        """One deterministic step-kernel call per distinct timestep over the rows that carry it (rows are sorted by
+        timestep first, so every call sees a contiguous block): `first` is the kernel's sample, `second` its model
+        output; returns prev_sample or the predicted x0, fp32, in the order of the input rows."""
+        _hip.require_gpu(first, "sample")
+        x, y = first.float().contiguous(), second.float().contiguous()
+        assert x.shape == y.shape, (tuple(x.shape), tuple(y.shape))
+        dim = x.shape[-1]
+        x2, y2 = x.reshape(-1, dim), y.reshape(-1, dim)
+        t = timesteps.to(x.device).long().flatten()
+        assert t.numel() >= 1 and x2.shape[0] % t.numel() == 0, (tuple(x.shape), tuple(timesteps.shape))
+        t = t.repeat_interleave(x2.shape[0] // t.numel())       # one timestep per leading entry of the samples
+        order = torch.argsort(t, stable=True)
+        xs, ys = x2[order].contiguous(), y2[order].contiguous()
+        steps, counts = torch.unique_consecutive(t[order], return_counts=True)
+        res = torch.empty_like(xs)
+        other = torch.empty_like(xs)
+        p = _hip.DenoiseParams(
+            guidance_scale=1.0, guidance_rescale=0.0, ddim_eta=0.0, epsilon_scaling=0.0, clip_noise=3.0e38,
+            init_noise_sigma=1.0, prediction_type=_hip.PRED[prediction_type], clip_sample=0, clip_sample_range=1.0,
+            thresholding=0, dynamic_thresholding_ratio=0.995, sample_max_value=1.0)
+        st, es, row0 = _hip.stream_ptr(x.device), xs.element_size() * dim, 0
+        for step, n in zip(steps.tolist(), counts.tolist()):
+            a = float(self.alphas_cumprod[int(step)])
+            off = row0 * es
+            prev, x0 = (other, res) if want_x0 else (res, other)
+            _hip.check(_hip.lib.lcmhip_ddim_cfg_step(xs.data_ptr() + off, ys.data_ptr() + off, None, prev.data_ptr() + off,
+                                                     x0.data_ptr() + off, n, dim, alpha_t_of(a), alpha_prev_of(a), p, None, st))
+            row0 += n
+        out = torch.empty_like(res)
+        out[order] = res
+        return out.reshape(x.shape)
+
+    def add_noise(self, original_samples: Tensor, noise: Tensor, timesteps: Tensor) -> Tensor:
+        """The forward noising process sqrt(a_t) x + sqrt(1 - a_t) noise with one timestep per leading entry of the
+        samples (reference ddim.py:512-540; a training-side member of the class), fp32.  Computed by the step kernel:
+        an epsilon-type deterministic step from alpha = 1 (where x0 is the sample itself) to alpha_prev = a_t with the
+        noise as the model output is sqrt(a_t) x + sqrt(1 - a_t) noise."""
+        return self._rows_by_timestep(original_samples, noise, timesteps, lambda a: 1.0, lambda a: a, "epsilon", False)
+
+    def get_velocity(self, sample: Tensor, noise: Tensor, timesteps: Tensor) -> Tensor:
+        """sqrt(a_t) noise - sqrt(1 - a_t) sample (reference ddim.py:542-559), fp32: the x0 that the step kernel
+        predicts for a v-type model output `sample` at the latent `noise`."""
+        return self._rows_by_timestep(noise, sample, timesteps, lambda a: a, lambda a: 0.0, "v_prediction", True)
+
     def get_epsilon(self, model_output: Tensor, sample: Tensor, timestep) -> Tensor:
         """The noise the model output implies for `sample` at `timestep` under the scheduler's prediction type
         (reference ddim.py:561-587), fp32.  Computed by the step kernel: with alpha_prev = 0 a deterministic DDIM step

@@ -654,3 +654,30 @@ def test_scheduler_get_epsilon(pred):
         got = a.get_epsilon(out.cuda(), x.cuda(), t).cpu()
         assert got.shape == want.shape and torch.isfinite(got).all()
         assert (got - want).abs().max() <= 1e-5 * max(1.0, float(want.abs().max())), (pred, t)
+
+
+def test_scheduler_add_noise_and_velocity():
+    """`DDIMScheduler.add_noise` / `get_velocity` (reference ddim.py:512-559) through the step kernel, one timestep per
+    leading entry of the samples, against the closed forms in fp32 -- flat rows, documents of several positions sharing
+    a timestep, a timestep per position, repeated and boundary timesteps (alpha_bar = 0 at the last step of the
+    zero-terminal-SNR schedule)."""
+    from lcm.nn.schedulers import DDIMScheduler, DDIMSchedulerConfig
+    sch = DDIMScheduler(DDIMSchedulerConfig(num_diffusion_train_steps=100))
+    ac = sch.alphas_cumprod.float().cpu()
+    g = torch.Generator().manual_seed(12)
+    cases = [((9, 1024), torch.tensor([5, 99, 0, 5, 42, 42, 7, 99, 63])),
+             ((4, 3, 1024), torch.tensor([17, 0, 99, 17])),
+             ((2, 5, 1024), torch.randint(0, 100, (2, 5), generator=g)),
+             ((1, 1024), torch.tensor([50]))]
+    for shape, t in cases:
+        x, nz = torch.randn(shape, generator=g) * 3.0, torch.randn(shape, generator=g)
+        a = ac[t.flatten()].repeat_interleave((x.numel() // 1024) // t.numel()).reshape(shape[:-1] + (1,))
+        want_noisy = a.sqrt() * x + (1 - a).sqrt() * nz
+        want_vel = a.sqrt() * nz - (1 - a).sqrt() * x
+        got_noisy = sch.add_noise(x.cuda(), nz.cuda(), t).cpu()
+        got_vel = sch.get_velocity(x.cuda(), nz.cuda(), t.cuda()).cpu()
+        assert got_noisy.shape == x.shape and got_vel.shape == x.shape
+        assert (got_noisy - want_noisy).abs().max() <= 2e-6 * float(want_noisy.abs().max()), shape
+        assert (got_vel - want_vel).abs().max() <= 2e-6 * float(want_vel.abs().max()), shape
+    with pytest.raises(RuntimeError):
+        sch.add_noise(torch.zeros(2, 1024), torch.zeros(2, 1024), torch.tensor([1, 2]))      # host tensors: no CPU path
