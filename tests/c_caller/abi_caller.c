@@ -256,5 +256,6 @@ int main(int argc, char** argv) {
     free(timesteps);
     printf("ok %d docs, context %d, %d steps, %d thread%s\n", n_docs, prompt_len + 1, n_steps, n_threads,
            n_threads == 1 ? "" : "s");
+    fflush(stdout);
     return 0;
 }
