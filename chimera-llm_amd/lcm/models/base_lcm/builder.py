@@ -203,15 +203,23 @@ class BaseLCModel(AbstractLCModel):
     def num_parameters(self) -> int:
         return sum(t.numel() for n, t in self._params.items() if "sonar_normalizer." not in n)
 
-    def _bind(self) -> None:
+    def model_desc(self) -> "_hip.ModelDesc":
+        """The lcmhip_model_desc this model was created from."""
         c, tc = self.config, self.config.lcm
         tower = tower_desc(tc)
         none = _hip.TowerDesc(num_layers=0)      # no denoiser tower: selects the base LCM in the library
-        desc = _hip.ModelDesc(sonar_dim=c.sonar_embed_dim, model_dim=c.model_dim, max_seq_len=c.max_seq_len,
+        return _hip.ModelDesc(sonar_dim=c.sonar_embed_dim, model_dim=c.model_dim, max_seq_len=c.max_seq_len,
                               timestep_freq_dim=TIMESTEP_FREQ_DIM, dtype=_hip.dtype_code(self.dtype), norm_eps=1e-5,
                               context=tower, denoiser=none,
                               embed_scale=float(c.model_dim ** 0.5) if c.frontend.scale_embeddings else 1.0,
                               postnet_activation=0 if c.postnet.activation_name is None else 1 + _hip.ACT[c.postnet.activation_name])
+
+    def bound_tensors(self) -> Dict[str, Tensor]:
+        """Every tensor bound into the library's weight table, by name (the state dict: a base LCM has no derived ones)."""
+        return dict(self._params)
+
+    def _bind(self) -> None:
+        desc = self.model_desc()
         _hip.check(_hip.lib.lcmhip_model_create(C.byref(desc), C.byref(self._handle)))
         code = _hip.dtype_code(self.dtype)
         for name, t in self._params.items():

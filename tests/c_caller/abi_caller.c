@@ -1,6 +1,7 @@
 /* A caller of the C ABI with nothing but the HIP runtime around it (no Python, no torch): reads a case file written by
  * tests/test_gpu_c_caller.py, builds the model from the tensors in it, runs
  *   reset -> context_append(prompt) -> denoise -> context_append(that sentence) -> denoise
+ * (a base LCM, i.e. a description without a denoiser tower: reset -> base_forward(prompt) -> base_forward(that sentence))
  * and writes the two generated sentences to the output file.  The test compares them bit for bit with what the Python
  * host gets from the same library calls.  With a thread count as third argument that many workers run the flow at the
  * same time, three times each, every worker with a session and a stream of its own on the one model; all must produce
@@ -79,7 +80,7 @@ struct flow {
     const lcmhip_denoise_params* params;
     const int32_t* timesteps;
     const float* alphas;
-    int32_t n_steps, n_train, step_ratio, n_docs, prompt_len, max_ctx, repeats;
+    int32_t n_steps, n_train, step_ratio, n_docs, prompt_len, max_ctx, repeats, base;
     float final_alpha;
     size_t D;
     const float* d_prompts;
@@ -102,14 +103,21 @@ static void* run_flow(void* arg) {
     for (int r = 0; r < w->repeats; ++r) {
         lcmhip_session* session = NULL;
         LCM_OK(lcmhip_session_create(w->model, w->n_docs, w->max_ctx, w->n_steps, 0u, workspace, ws_bytes, &session));
-        LCM_OK(lcmhip_session_set_schedule(session, w->timesteps, w->n_steps, w->alphas, w->n_train, w->final_alpha,
-                                           w->step_ratio, w->params, stream));
         LCM_OK(lcmhip_session_reset(session, w->n_docs, stream));
-        LCM_OK(lcmhip_context_append(session, w->d_prompts, w->prompt_len, 0, stream));
-        LCM_OK(lcmhip_denoise(session, w->d_noise, d_out, NULL, stream));
-        /* the generated sentence becomes the next context position (n_docs, 1, sonar_dim) */
-        LCM_OK(lcmhip_context_append(session, d_out, 1, 0, stream));
-        LCM_OK(lcmhip_denoise(session, w->d_noise + row, d_out + row, NULL, stream));
+        if (w->base) {
+            /* base LCM: the prediction after the prompt, sampled with the case's noise at temperature 0.5, then that
+             * sentence as the next position (n_docs, 1, sonar_dim) */
+            LCM_OK(lcmhip_base_forward(session, w->d_prompts, w->prompt_len, 0, w->d_noise, 0.5f, 0, d_out, stream));
+            LCM_OK(lcmhip_base_forward(session, d_out, 1, 0, w->d_noise + row, 0.5f, 0, d_out + row, stream));
+        } else {
+            LCM_OK(lcmhip_session_set_schedule(session, w->timesteps, w->n_steps, w->alphas, w->n_train, w->final_alpha,
+                                               w->step_ratio, w->params, stream));
+            LCM_OK(lcmhip_context_append(session, w->d_prompts, w->prompt_len, 0, stream));
+            LCM_OK(lcmhip_denoise(session, w->d_noise, d_out, NULL, stream));
+            /* the generated sentence becomes the next context position (n_docs, 1, sonar_dim) */
+            LCM_OK(lcmhip_context_append(session, d_out, 1, 0, stream));
+            LCM_OK(lcmhip_denoise(session, w->d_noise + row, d_out + row, NULL, stream));
+        }
         HIP_OK(hipStreamSynchronize(stream));
         if (lcmhip_session_context_len(session) != w->prompt_len + 1 || lcmhip_session_num_active(session) != w->n_docs) {
             fprintf(stderr, "session reports context %d, %d active\n", lcmhip_session_context_len(session),
@@ -221,6 +229,7 @@ int main(int argc, char** argv) {
         w->n_train = n_train; w->final_alpha = final_alpha; w->step_ratio = step_ratio; w->n_docs = n_docs;
         w->prompt_len = prompt_len; w->max_ctx = max_ctx; w->D = D; w->d_prompts = d_prompts; w->d_noise = d_noise;
         w->repeats = n_threads > 1 ? 3 : 1;
+        w->base = desc.denoiser.num_layers == 0;
         w->out = (float*)xmalloc(2 * row_bytes);
     }
     if (n_threads == 1) {

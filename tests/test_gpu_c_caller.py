@@ -10,7 +10,7 @@ import subprocess
 import pytest
 import torch
 
-from parity_utils import DEFAULT_OPTS, mini_config
+from parity_utils import DEFAULT_OPTS, base_config, mini_config
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CALLER = os.path.join(ROOT, "tests", "c_caller", "abi_caller")
@@ -103,3 +103,46 @@ def test_c_caller_without_python_gets_the_same_bits(tmp_path, dtype):
     assert run.stdout.startswith("ok 5 docs, context 8") and "4 threads" in run.stdout, run.stdout
     got = torch.frombuffer(bytearray(out4.read_bytes()), dtype=torch.float32).reshape(2, n_docs, 1024)
     assert torch.equal(got, want), float((got - want).abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_c_caller_base_lcm(tmp_path, dtype):
+    """The base LCM through `lcmhip_base_forward` from the C process: the sampled prediction after a prompt, then after
+    that sentence as one more position -- the bits of the Python host, from one thread and from four."""
+    from lcm import _hip
+    from lcm.models.base_lcm import create_base_lcm_model
+    from lcm.models.two_tower_diffusion_lcm.builder import DeviceSession
+
+    if not os.path.exists(CALLER):
+        subprocess.run(["make", "-C", os.path.dirname(CALLER), "abi_caller"], check=True, capture_output=True)
+    dev = torch.device("cuda", 0)
+    model = create_base_lcm_model(base_config("mini_base_lcm"), device=dev, dtype=dtype, seed=2)
+    n_docs, prompt_len, max_ctx = 5, 7, 16
+    g = torch.Generator().manual_seed(13)
+    prompts = (torch.randn(n_docs, prompt_len, 1024, generator=g) * 0.006).to(dev)
+    noise = torch.randn(2, n_docs, 1024, generator=g).to(dev)
+
+    sess = DeviceSession(model, n_docs, max_ctx, 1)
+    sess.reset(n_docs)
+    first = sess.base_forward(prompts, normalized=False, noise=noise[0], temperature=0.5, all_positions=False)
+    second = sess.base_forward(first.unsqueeze(1), normalized=False, noise=noise[1], temperature=0.5, all_positions=False)
+    torch.cuda.current_stream().synchronize()
+    want = torch.stack([first, second]).cpu()
+    assert torch.isfinite(want).all() and not torch.equal(want[0], want[1])
+
+    case = tmp_path / "case.bin"
+    write_case(case, model, _hip.DenoiseParams(), [0], [1.0], 1.0, 1, prompts, noise, max_ctx)
+    for threads in ("1", "4"):
+        out = tmp_path / f"out{threads}.bin"
+        run = subprocess.run([CALLER, str(case), str(out), threads], capture_output=True, text=True, timeout=240)
+        assert run.returncode == 0, (run.returncode, run.stdout[-2000:], run.stderr[-2000:])
+        assert run.stdout.startswith("ok 5 docs, context 8, 1 steps"), run.stdout
+        got = torch.frombuffer(bytearray(out.read_bytes()), dtype=torch.float32).reshape(2, n_docs, 1024)
+        assert torch.equal(got, want), (threads, float((got - want).abs().max()))
+    keep = os.environ.get("LCM_CASE_DIR")
+    if keep:
+        import shutil
+        tag = "base_bf16" if dtype == torch.bfloat16 else "base_fp32"
+        shutil.copy(case, os.path.join(keep, f"case_{tag}.bin"))
+        with open(os.path.join(keep, f"want_{tag}.bin"), "wb") as f:
+            f.write(want.contiguous().numpy().tobytes())
