@@ -18,7 +18,7 @@ import torch.nn.functional as F
 
 import oracle
 from oracle.archs import SchedulerConfig
-from oracle.model import KVCache, causal_mask, rope, rope_explicit, sdpa, sinusoidal_positions
+from oracle.model import KVCache, causal_mask, linear, rope, rope_explicit, sdpa, sinusoidal_positions
 from oracle.weights import num_parameters, synthetic_noise, synthetic_prompts
 
 OPTS = dict(guidance_scale=3.0, guidance_rescale=0.7, initial_noise_scale=0.6, eos_threshold=None)
@@ -417,3 +417,68 @@ def test_contextualizer_options_cached_equals_full(order, final, pos, swiglu):
     f = torch.exp(torch.arange(4, dtype=torch.float64) * (-math.log(10000.0) / 3))
     want = torch.cat([torch.sin(torch.tensor([[3.0], [4.0]], dtype=torch.float64) * f), torch.cos(torch.tensor([[3.0], [4.0]], dtype=torch.float64) * f)], -1)
     assert torch.allclose(tab.double(), want, atol=1e-6)
+
+
+def test_decoder_stack_against_an_independent_llama_implementation():
+    """The oracle's pre-norm RMSNorm / RoPE / SwiGLU decoder stack (the base LCM's `lcm` tower: frontend projection,
+    three layers, final norm) against Hugging Face `transformers`' LlamaModel, an implementation written by other
+    people, fed the same weights.  The one convention that differs is the rotary pairing: the oracle follows
+    fairseq2 / the original LLaMA code (consecutive pairs (2i, 2i + 1)), transformers rotates half against half, and
+    the two are equal once the rows of W_q / W_k (and their biases) are permuted even-indices-first inside every head
+    -- the permutation transformers' own LLaMA checkpoint converter applies.  Everything else (RMSNorm cast order,
+    causal mask, softmax scale, SwiGLU gate order, residuals) must agree as it stands."""
+    transformers = pytest.importorskip("transformers")
+    cfg = oracle.get_base_arch("mini_base_lcm")
+    tc = cfg.lcm
+    sd = oracle.init_state_dict(cfg, seed=6, qk_gain=2.0)
+    inner = sd["lcm.layers.0.ffn.inner_proj.weight"].shape[0]
+    hf_cfg = transformers.LlamaConfig(
+        vocab_size=8, hidden_size=cfg.model_dim, intermediate_size=inner, num_hidden_layers=tc.num_layers,
+        num_attention_heads=tc.num_heads, num_key_value_heads=tc.num_heads, rms_norm_eps=cfg.norm_eps,
+        rope_theta=tc.rope_theta, attention_bias=True, mlp_bias=True, max_position_embeddings=64,
+        attn_implementation="eager")
+    hf = transformers.LlamaModel(hf_cfg).eval()
+
+    def halves_first(w):        # rows (head, pair, 2) -> (head, 2, pair)
+        hd = cfg.model_dim // tc.num_heads
+        return w.reshape(tc.num_heads, hd // 2, 2, *w.shape[1:]).transpose(1, 2).reshape(w.shape)
+
+    with torch.no_grad():
+        for i, layer in enumerate(hf.layers):
+            p = f"lcm.layers.{i}"
+            a = layer.self_attn
+            a.q_proj.weight.copy_(halves_first(sd[p + ".self_attn.q_proj.weight"]))
+            a.q_proj.bias.copy_(halves_first(sd[p + ".self_attn.q_proj.bias"]))
+            a.k_proj.weight.copy_(halves_first(sd[p + ".self_attn.k_proj.weight"]))
+            a.k_proj.bias.copy_(halves_first(sd[p + ".self_attn.k_proj.bias"]))
+            a.v_proj.weight.copy_(sd[p + ".self_attn.v_proj.weight"])
+            a.v_proj.bias.copy_(sd[p + ".self_attn.v_proj.bias"])
+            a.o_proj.weight.copy_(sd[p + ".self_attn.output_proj.weight"])
+            a.o_proj.bias.copy_(sd[p + ".self_attn.output_proj.bias"])
+            layer.input_layernorm.weight.copy_(sd[p + ".self_attn_layer_norm.weight"])
+            layer.post_attention_layernorm.weight.copy_(sd[p + ".ffn_layer_norm.weight"])
+            layer.mlp.gate_proj.weight.copy_(sd[p + ".ffn.gate_proj.weight"])
+            layer.mlp.gate_proj.bias.copy_(sd[p + ".ffn.gate_proj.bias"])
+            layer.mlp.up_proj.weight.copy_(sd[p + ".ffn.inner_proj.weight"])
+            layer.mlp.up_proj.bias.copy_(sd[p + ".ffn.inner_proj.bias"])
+            layer.mlp.down_proj.weight.copy_(sd[p + ".ffn.output_proj.weight"])
+            layer.mlp.down_proj.bias.copy_(sd[p + ".ffn.output_proj.bias"])
+        hf.norm.weight.copy_(sd["lcm.layer_norm.weight"])
+
+    model = oracle.OracleBaseLCM(cfg, sd)
+    torch.manual_seed(2)
+    x_norm = torch.randn(3, 11, cfg.sonar_dim)
+    with torch.no_grad():
+        want = model.forward(x_norm)                                           # frontend + stack + final norm + postnet
+        hidden = hf(inputs_embeds=linear(x_norm, sd, "frontend.pre_linear")).last_hidden_state
+        got = linear(hidden, sd, "postnet.fc")
+    assert got.shape == want.shape
+    assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max())), float((got - want).abs().max())
+    # and position by position through the oracle's KV cache (what the generators use)
+    cache = KVCache(16)
+    with torch.no_grad():
+        steps = []
+        for j in range(x_norm.shape[1]):
+            steps.append(model.forward(x_norm[:, j:j + 1], cache))
+            cache.increment_step_nr(1)
+    assert float((torch.cat(steps, dim=1) - got).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
