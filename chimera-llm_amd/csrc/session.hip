@@ -1179,14 +1179,20 @@ static int append_impl(lcmhip_session* s, const float* x, int32_t n_tokens, int3
                 ProfScope ps(&s->prof, "base.out", R * (double)D * 8.0, 0.0, st);
                 float* g_out = bo->out + (size_t)d0 * n_out_pos * D;
                 const float* g_noise = bo->noise ? bo->noise + (size_t)d0 * n_out_pos * D : nullptr;
+                // inputs handed over in normalized space get their predictions back in normalized space: BaseLCModel.forward
+                // (builder.py:94-124) has no normalizer in it, predict_next_sentence (:150-165) has it on both sides
+                const void* center = normalized ? nullptr : m->center;
+                const void* scale = normalized ? nullptr : m->scale;
+                const void* cmin = normalized ? nullptr : m->clip_min;
+                const void* cmax = normalized ? nullptr : m->clip_max;
                 if (d.dtype == LCMHIP_BF16)
-                    hipLaunchKernelGGL((k_base_out<bf16_t>), dim3(R), dim3(128), 0, st, s->f32tmp, g_noise, (const bf16_t*)m->center,
-                                       (const bf16_t*)m->scale, g_out, D, sc, n_tokens, j0, bo->all, bo->temperature,
-                                       (const bf16_t*)m->clip_min, (const bf16_t*)m->clip_max, d.postnet_activation);
+                    hipLaunchKernelGGL((k_base_out<bf16_t>), dim3(R), dim3(128), 0, st, s->f32tmp, g_noise, (const bf16_t*)center,
+                                       (const bf16_t*)scale, g_out, D, sc, n_tokens, j0, bo->all, bo->temperature,
+                                       (const bf16_t*)cmin, (const bf16_t*)cmax, d.postnet_activation);
                 else
-                    hipLaunchKernelGGL((k_base_out<float>), dim3(R), dim3(128), 0, st, s->f32tmp, g_noise, (const float*)m->center,
-                                       (const float*)m->scale, g_out, D, sc, n_tokens, j0, bo->all, bo->temperature,
-                                       (const float*)m->clip_min, (const float*)m->clip_max, d.postnet_activation);
+                    hipLaunchKernelGGL((k_base_out<float>), dim3(R), dim3(128), 0, st, s->f32tmp, g_noise, (const float*)center,
+                                       (const float*)scale, g_out, D, sc, n_tokens, j0, bo->all, bo->temperature,
+                                       (const float*)cmin, (const float*)cmax, d.postnet_activation);
                 LCM_HIP_CHECK(hipGetLastError());
             }
         }

@@ -283,7 +283,8 @@ class BaseLCModel(AbstractLCModel):
                 self.release_session(sess)
 
     def forward(self, batch: EmbeddingsBatch, state_bag: Optional[LCMIncrementalStateBag] = None, **kwargs) -> EmbeddingsBatch:
-        """Frontend, causal decoder and postnet on already-normalized inputs (reference :94-124)."""
+        """Frontend, causal decoder and postnet (reference :94-124): no normalizer on either side, so inputs in the
+        normalizer's space give predictions in the normalizer's space."""
         if batch.padding_mask is not None:
             raise ValueError("the HIP decoder takes unpadded positions (the generators never pad them)")
         out = self._run(batch.seqs, state_bag, normalized=True, noise=None, temperature=0.0)

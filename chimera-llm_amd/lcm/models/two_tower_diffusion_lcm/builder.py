@@ -381,7 +381,8 @@ class DeviceSession:
     def base_forward(self, x: Tensor, *, normalized: bool, noise: Optional[Tensor], temperature: float,
                      all_positions: bool, want_output: bool = True) -> Optional[Tensor]:
         """Base LCM: appends the s positions of x (n_active, s, D) and returns the predictions, fp32, for every
-        position (n_active, s, D) or for the last one (n_active, D); None when only the cache is wanted."""
+        position (n_active, s, D) or for the last one (n_active, D); None when only the cache is wanted.  Raw embeddings
+        in, raw predictions out; with `normalized` both sides stay in the normalizer's space (the model's `forward`)."""
         _hip.require_gpu(x, "input embeddings")
         x32 = self._to_model_space(x.float().contiguous(), normalized)
         assert x32.dim() == 3 and x32.shape[0] == self.num_active, (tuple(x32.shape), self.num_active)
@@ -395,7 +396,7 @@ class DeviceSession:
             assert nz.numel() == out.numel(), "noise must have the shape of the output"
         _hip.check(_hip.lib.lcmhip_base_forward(self._h, _hip.ptr(x32), x32.shape[1], int(normalized), _hip.ptr(nz),
                                                 float(temperature), int(all_positions), _hip.ptr(out), self._stream()))
-        return self._from_model_space(out)
+        return out if normalized else self._from_model_space(out)      # normalized in, normalized out
 
     def denoise(self, noise: Tensor, trace: Optional[Tensor] = None, variance_noise: Optional[Tensor] = None) -> Tensor:
         """noise: (n_active, D) N(0, 1) draws -> next sentence embedding (n_active, D) fp32.  `variance_noise`

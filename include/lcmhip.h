@@ -221,7 +221,9 @@ int lcmhip_context_append(lcmhip_session* s, const float* x, int32_t n_tokens, i
  * SonarNormalizer.normalize (skipped when `normalized` != 0 or the model has no normalizer), LCMFrontend.forward
  * (base_lcm/frontend.py:154-183), the KV-cached causal decoder (lcm/nn/transformer/decoder.py:131-176), the
  * postnet Projection (lcm/nn/projection.py:80-86), `+ temperature * noise` when `noise` is not NULL and
- * temperature > 0 (builder.py:158-160, with host-supplied N(0,1) draws instead of randn_like), and denormalize.
+ * temperature > 0 (builder.py:158-160, with host-supplied N(0,1) draws instead of randn_like), and denormalize
+ * (skipped under the same condition as normalize: `normalized` != 0 is BaseLCModel.forward, builder.py:94-124, which
+ * has no normalizer on either side).
  * `x` is (n_active, n_tokens, sonar_dim) fp32: the next n_tokens positions of every active document, appended to
  * the session's KV cache.  `out` receives (n_active, n_tokens, sonar_dim) fp32 when all_positions != 0, else the
  * prediction after the last position only, (n_active, sonar_dim); `noise` has the shape of `out`.

@@ -445,3 +445,36 @@ def test_reference_next_sentence_prediction():
     random_prediction = model.predict_next_sentence(batch, sample=True, temperature=0.01).seqs
     assert random_prediction.shape == x.shape
     assert not torch.allclose(random_prediction, first)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_forward_stays_in_normalizer_space(dtype):
+    """`BaseLCModel.forward` has no normalizer on either side (reference builder.py:94-124); `predict_next_sentence`
+    wraps it in normalize / denormalize (:150-165).  So predict(raw) == denormalize(forward(normalize(raw))) with the
+    model's own normalizer, and forward against the oracle's forward directly."""
+    from lcm.datasets.batch import EmbeddingsBatch
+    cfg, sd, x, _ = make_base_problem("mini_base_lcm", 3, 6, 1, seed=9, norm_jitter=0.2)
+    from lcm.models.base_lcm import create_base_lcm_model
+    model = create_base_lcm_model(base_config("mini_base_lcm"), device="cuda:0", dtype=dtype)
+    model.load_state_dict(sd)
+    normalizer = model.frontend.sonar_normalizer
+    raw = EmbeddingsBatch(x.cuda().to(dtype), None)
+    predicted = model.predict_next_sentence(raw).seqs.float()
+    inner = model.forward(raw.normalize_seqs(normalizer))
+    by_hand = inner.denormalize_seqs(normalizer).seqs.float()
+    scale = sd["frontend.sonar_normalizer.scale"].cuda()
+    center = sd["frontend.sonar_normalizer.center"].cuda()
+    if dtype == torch.float32:
+        assert float(((predicted - by_hand) / scale).abs().max()) <= 1e-5
+    else:       # the stand-alone normalizer hands bf16 rows to forward, the fused path rounds once: two bf16 evaluations
+        a, b = (predicted - center) / scale, (by_hand - center) / scale
+        assert float(torch.nn.functional.cosine_similarity(a, b, dim=-1).min()) >= BF16_COS
+    om = oracle.OracleBaseLCM(cfg, {k: (oracle.r16(v) if dtype == torch.bfloat16 else v) for k, v in sd.items()})
+    xn = om.normalize(x)
+    want = om.forward(oracle.r16(xn) if dtype == torch.bfloat16 else xn)
+    got = inner.seqs.float().cpu()
+    cos = float(torch.nn.functional.cosine_similarity(got, want, dim=-1).min())
+    if dtype == torch.float32:
+        assert float((got - want).abs().max()) <= FP32_MAX_ABS and cos >= FP32_COS, (float((got - want).abs().max()), cos)
+    else:
+        assert cos >= BF16_COS, cos

@@ -430,7 +430,7 @@ def test_decoder_stack_against_an_independent_llama_implementation():
     transformers = pytest.importorskip("transformers")
     cfg = oracle.get_base_arch("mini_base_lcm")
     tc = cfg.lcm
-    sd = oracle.init_state_dict(cfg, seed=6, qk_gain=2.0)
+    sd = oracle.init_state_dict(cfg, seed=6, qk_gain=2.0, norm_jitter=0.1, b_std=0.05)
     inner = sd["lcm.layers.0.ffn.inner_proj.weight"].shape[0]
     hf_cfg = transformers.LlamaConfig(
         vocab_size=8, hidden_size=cfg.model_dim, intermediate_size=inner, num_hidden_layers=tc.num_layers,
