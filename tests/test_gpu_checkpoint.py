@@ -4,6 +4,7 @@
 checkpoints cast to the requested dtype, `model_config` overrides, and the normalizer taken from its own card when
 the checkpoint does not carry it."""
 
+import os
 import pytest
 import torch
 import yaml
@@ -125,3 +126,19 @@ def test_training_directory_and_checkpoint_path_as_model_names(tmp_path):
     assert torch.equal(m.state_dict()[key].cpu(), sds[20][key])
     with pytest.raises(ValueError, match="not a valid model directory"):
         load_model_with_overrides(tmp_path / "nothing_here", model_type="base_lcm")
+
+
+def test_reference_sonar_normalizer_loads_by_card_name():
+    """The reference's own test (tests/units/models/test_lcm_architecture.py:34-35), call for call, plus what the card
+    must deliver: the fixture's statistics on the device, and a normalize / denormalize round trip through them."""
+    from lcm.models.sonar_normalizer import SonarNormalizerConfig, create_sonar_normalizer
+    from lcm.models.sonar_normalizer.loader import load_sonar_normalizer_model
+    model = load_sonar_normalizer_model("dummy_sonar_normalizer", device="cuda:0", dtype=torch.float32)
+    assert model is not None
+    blob = torch.load(os.path.join(os.path.dirname(__file__), "golden", "dummy_normalizer.pt"), map_location="cpu", weights_only=True)
+    blob = blob["model"] if "model" in blob else blob
+    assert torch.equal(model.center.cpu(), blob["center"].float()) and torch.equal(model.scale.cpu(), blob["scale"].float())
+    x = torch.randn(7, 1024, generator=torch.Generator().manual_seed(1)).cuda() * 0.01
+    assert float((model.denormalize(model.normalize(x)) - x).abs().max()) <= 1e-6
+    fresh = create_sonar_normalizer(SonarNormalizerConfig(dim=1024), device="cuda:0", dtype=torch.float32)
+    assert fresh.center.shape == (1024,) and fresh.config.dim == 1024
