@@ -25,7 +25,7 @@ ORDER = {"pre": 0, "post": 1, "normformer": 2}   # LCMHIP_ORDER_*
 PRED = {"sample": 0, "epsilon": 1, "v_prediction": 2}
 EPI_STORE, EPI_STORE_F32, EPI_RELU, EPI_SWIGLU, EPI_RESID = 0, 1, 2, 3, 4
 STATIC_SCRATCH_BYTES = 16 << 20      # LCMHIP_STATIC_SCRATCH_BYTES of include/lcmhip.h
-ABI_VERSION = 400                    # LCMHIP_ABI_VERSION of include/lcmhip.h: the layouts and signatures bound below
+ABI_VERSION = 401                    # LCMHIP_ABI_VERSION of include/lcmhip.h: the layouts and signatures bound below
 # LCMHIP_SESSION_* flags of lcmhip_session_workspace_bytes / lcmhip_session_create
 SESSION_KEEP_CONTEXT, SESSION_SEPARATE_QKV, SESSION_SEPARATE_ROPE, SESSION_NO_GRAPH = 1, 2, 4, 8
 

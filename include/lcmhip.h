@@ -33,12 +33,13 @@ extern "C" {
 #endif
 
 /* Version of this ABI (struct layouts and signatures).  lcmhip_version() returns the value the library was built
- * with; a caller built against another value must not bind.  300 -> 400: lcmhip_tower_desc.norm_order,
+ * with; a caller built against another value must not bind.  400 -> 401: lcmhip_base_forward with normalized != 0
+ * returns its predictions in the normalizer's space (it applied the inverse normalizer before).  300 -> 400: lcmhip_tower_desc.norm_order,
  * no_final_norm and scale_residual, LCMHIP_POS_SINE, LCMHIP_ACT_PRELU, lcmhip_model_desc.postnet_activation,
  * lcmhip_rfft_pack; 200 -> 300: lcmhip_session_workspace_bytes and
  * lcmhip_session_create take `flags`, lcmhip_static_init added, lcmhip_tower_desc.ffn_activation; 100 -> 200: lcmhip_tower_desc.qk_layernorm,
  * thresholding fields of lcmhip_denoise_params, variance_noise of lcmhip_ddim_cfg_step. */
-#define LCMHIP_ABI_VERSION 400
+#define LCMHIP_ABI_VERSION 401
 
 #define LCMHIP_OK 0
 #define LCMHIP_ERR_INVALID (-1)     /* bad argument / shape the kernels do not support */
