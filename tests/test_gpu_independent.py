@@ -19,6 +19,11 @@ def _config(name):
             model_dim=256, max_seq_len=512, sonar_normalizer_name="dummy_sonar_normalizer",
             lcm=TransformerConfig(num_layers=3, num_attn_heads=2, ffn_inner_dim=1024, use_swiglu=True,
                                   layer_normalization_style="rms", pos_embedding_style="rope", mha_output_proj_bias=True))
+    if name == "big":                  # the 1.6B arch's widths on two layers: with 8 x 128 positions the matrix-core products
+        return BaseLCModelConfig(      # and the tiled prefill attention are the kernels that run
+            model_dim=2048, max_seq_len=512, sonar_normalizer_name="dummy_sonar_normalizer",
+            lcm=TransformerConfig(num_layers=2, num_attn_heads=16, ffn_inner_dim=8192, use_swiglu=True,
+                                  layer_normalization_style="rms", pos_embedding_style="rope", mha_output_proj_bias=True))
     return BaseLCModelConfig(          # "wide": 8 heads, the GLU width rounding of a 4096-wide FFN
         model_dim=1024, max_seq_len=512, sonar_normalizer_name="dummy_sonar_normalizer",
         lcm=TransformerConfig(num_layers=2, num_attn_heads=8, ffn_inner_dim=4096, use_swiglu=True,
@@ -32,7 +37,7 @@ def _llama_for(cfg, sd, tower="lcm"):
     hf_cfg = transformers.LlamaConfig(
         vocab_size=8, hidden_size=d, intermediate_size=sd[f"{tower}.layers.0.ffn.inner_proj.weight"].shape[0],
         num_hidden_layers=tc.num_layers, num_attention_heads=H, num_key_value_heads=H, rms_norm_eps=1e-5,
-        rope_theta=10000.0, attention_bias=True, mlp_bias=True, max_position_embeddings=64, attn_implementation="eager")
+        rope_theta=10000.0, attention_bias=True, mlp_bias=True, max_position_embeddings=256, attn_implementation="eager")
     hf = transformers.LlamaModel(hf_cfg).eval()
 
     def halves_first(w):        # rows (head, pair, 2) -> (head, 2, pair)
@@ -110,7 +115,8 @@ def test_two_tower_contextualizer_against_transformers_llama(dtype):
     check(out.seqs if hasattr(out, "seqs") else out)
 
 
-@pytest.mark.parametrize("name,dtype", [("mini", torch.float32), ("wide", torch.float32), ("mini", torch.bfloat16)])
+@pytest.mark.parametrize("name,dtype", [("mini", torch.float32), ("wide", torch.float32), ("mini", torch.bfloat16),
+                                        ("big", torch.bfloat16), ("big", torch.float32)])
 def test_base_lcm_forward_against_transformers_llama(name, dtype):
     from lcm.datasets.batch import EmbeddingsBatch
     from lcm.models.base_lcm import create_base_lcm_model
@@ -127,7 +133,8 @@ def test_base_lcm_forward_against_transformers_llama(name, dtype):
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
     hf = _llama_for(cfg, sd)
 
-    x = torch.randn(3, 11, cfg.sonar_embed_dim, generator=g)          # already-normalized inputs
+    shape = (8, 128) if name == "big" else (3, 11)
+    x = torch.randn(*shape, cfg.sonar_embed_dim, generator=g)         # already-normalized inputs
     got = model.forward(EmbeddingsBatch(x.cuda().to(dtype), None)).seqs.float().cpu()
     xin = x.to(dtype).float()
     scale = cfg.model_dim ** 0.5 if cfg.frontend.scale_embeddings else 1.0
@@ -142,6 +149,8 @@ def test_base_lcm_forward_against_transformers_llama(name, dtype):
     else:
         assert cos >= 0.999, (err, cos)
 
+    if name == "big":
+        return
     # position by position through the KV cache (the generators' path): the same answers
     bag = LCMIncrementalStateBag(16)
     steps = []
